@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the per-pixel Monte-Carlo sampling path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one frame of synthetic input (the seeded Shirley cover scene): every
+rank renders its round-robin 8x8 tiles of the frame from the HBM-resident scene, one gather brings the tiles to rank 0,
+rank 0 assembles + quantises.  At N=1 the workload is BASELINE configs[1] (800x400x64spp, cover scene n=11, depth 50);
+at N>1 the per-GPU work is kept fixed (weak scaling): the same frame at 64*N spp.  Inputs and outputs stay in HBM.
+One JSON line is printed by rank 0; see DESIGN.md for the roofline arithmetic."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (nx, ny, ns, n, moving, mix)
+    "C1": (200, 100, 4, 11, False, (0.8, 0.95)),
+    "C2": (800, 400, 64, 11, False, (0.8, 0.95)),
+    "C2m": (800, 400, 64, 11, True, (0.8, 0.95)),
+    "C3": (1920, 1080, 256, 50, False, (0.8, 0.95)),
+    "C4": (3840, 2160, 512, 11, False, (0.8, 0.95)),
+    "C5": (1920, 1080, 4096, 11, False, (0.1, 0.2)),
+}
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_PEAK_TFLOPS = 78.6     # vector FP64 (spec)
+FP32_PEAK_TFLOPS = 157.3
+
+
+def cpu_baseline(flat, nx, ny, ns, budget_s=12.0):
+    """The CPU oracle (oracle/rt_oracle.c, a restatement of the reference path -- NOT the JVM) timed on this box's host
+    cores on a bounded sample of the same workload: evenly spread 2-row bands of the frame at full spp."""
+    from oracle.oracle import Oracle
+    orc = Oracle("f64")
+    cores = os.cpu_count() or 1
+    bands = [(0, y, nx, y + 2) for y in range(ny // 20, ny - 1, max(2, ny // 10))]
+    t0 = time.time()
+    orc.render(flat, nx, ny, min(ns, 4), 50, 0x5EED0002, region=bands[len(bands) // 2], nthreads=cores)
+    probe = max(time.time() - t0, 1e-3) * (ns / min(ns, 4))
+    n_bands = max(1, min(len(bands), int(budget_s / probe)))
+    step = max(1, len(bands) // n_bands)
+    use = bands[::step][:n_bands]
+    samples, t0 = 0, time.time()
+    for b in use:
+        orc.render(flat, nx, ny, ns, 50, 0x5EED0002, region=b, nthreads=cores)
+        samples += (b[2] - b[0]) * (b[3] - b[1]) * ns
+    dt = time.time() - t0
+    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d two-row bands of the %dx%d frame at %d spp (%d samples, %.1f s)" % (len(use), nx, ny, ns, samples, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import raytrace_clj_amd as r
+    from raytrace_clj_amd import dist as rdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    nx, ny, ns1, n, moving, mix = CONFIGS[args.config]
+    ns = ns1 * world  # weak scaling: per-GPU work fixed
+    scene = r.scene.make_random_scene(nx, ny, n, moving, mix=mix)
+    flat = r.flatten.flatten(scene)
+    ctx = r.Context(local_rank, timing=True)
+    if args.blocks_per_cu:
+        ctx.set_option("blocks_per_cu", args.blocks_per_cu)
+    ds = r.DeviceScene(flat, ctx=ctx)
+    tr = rdist.TileRenderer(ds, nx, ny, rank, world)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(ns, precision=args.precision)
+    barrier()
+    ctx.last_trace_ms()  # reset the event window
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(ns, precision=args.precision)
+    barrier()
+    dt = time.perf_counter() - t0
+    trace_ms, launches = ctx.last_trace_ms()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        seg = tr.counters[:1].clone()
+        dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+        segments = int(seg.item())
+    else:
+        segments = int(tr.counters[0].item())
+
+    if rank == 0:
+        samples = nx * ny * ns
+        ms_per_step = dt / args.steps * 1e3
+        value = samples / (dt / args.steps) / 1e6
+        # roofline of the dominant kernel (trace_kernel) on rank 0: SURVEY.md 8(d) algorithmic figures per launch
+        rec = 32 if args.precision == "f64" else 16
+        seg_local = int(tr.counters[0].item())
+        n_prims = flat.n_prims
+        launches_per_step = max(1, launches // max(1, args.steps))
+        launch_s = trace_ms / 1e3 / max(1, launches)
+        pix_local = int(tr.counters[1].item())
+        bytes_alg = (seg_local * n_prims * rec / 256.0 + pix_local * 12.0) / launches_per_step
+        flops_alg = seg_local * (n_prims * 20.0 + 120.0) / launches_per_step
+        achieved = bytes_alg / launch_s / 1e9
+        peak_t = FP64_PEAK_TFLOPS if args.precision == "f64" else FP32_PEAK_TFLOPS
+        out = {
+            "metric": "Msamples/sec (nx*ny*ns)", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "%s: %dx%dx%dspp Shirley cover scene n=%d (%d spheres%s), depth 50, thin-lens camera, "
+                                   "seeded counter RNG; tiles dealt round-robin to %d GPU(s)" % (
+                                       args.config, nx, ny, ns, n, n_prims, ", moving" if moving else "", world),
+                       "nx": nx, "ny": ny, "ns": ns, "spheres": n_prims, "depth": 50, "segments_per_sample": round(segments / samples, 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "trace_kernel", "launch_ms": round(launch_s * 1e3, 4), "launches_per_step": launches_per_step,
+                         "algorithmic_bytes_per_launch": round(bytes_alg),
+                         "valu": {"achieved": round(flops_alg / launch_s / 1e12, 3), "peak": peak_t, "unit": "TFLOP/s",
+                                  "frac": round(flops_alg / launch_s / 1e12 / peak_t, 5),
+                                  "note": "the sphere scan is VALU-bound, not HBM-bound (SURVEY.md 8d); flops = S*(20N+120)"}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(flat, nx, ny, ns)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+/*
+ * rtmi.h -- C-ABI of librtmi.so: raytrace-clj's per-pixel Monte-Carlo sampling path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  The reference (gonewest818/raytrace-clj) has no FFI of its own; the
+ * seam this library replaces is the body of the render loop
+ *     src/raytrace_clj/core.clj:100-108   (cp/upmap over tiled-coords -> pixel -> set-pixel)
+ * i.e. everything `pixel` (core.clj:43-57) and `color` (core.clj:17-41) call through the Hitable /
+ * Shader / Texture / Camera protocols (hitable.clj:7-10, shader.clj:22-24, texture.clj:8-9,
+ * camera.clj:5-6).  A host (Clojure via JNA, Python via ctypes, C++) flattens a
+ * {:camera c :world w} scene (scene.clj:321,331) into the arrays below and calls rtmi_render.
+ * See INTEGRATION.md for the JNA stub.
+ *
+ * Conventions (normative):
+ *   - plain C symbols, no exceptions cross the boundary;
+ *   - every call returns int: 0 = RTMI_OK, < 0 = error class; rtmi_last_error() gives the text
+ *     (thread-local, library-owned, valid until the next failing call on that thread);
+ *   - rtmi_ctx / rtmi_scene are opaque, created and destroyed by the library only;
+ *   - every host array argument is caller-allocated, caller-owned and only read/written for the
+ *     duration of the call (the library keeps no host pointers);
+ *   - host-side scalars and arrays are double / int32 whatever precision the kernels compute in;
+ *   - a context is not re-entrant; distinct contexts may be driven from distinct threads;
+ *   - framebuffers are row-major, RGB interleaved, ROW 0 = TOP, i.e. after the reference's flip
+ *     y_out = ny-1-j (core.clj:105).
+ *
+ * Flat scene layout (what a flattener over the reference's records produces):
+ *   primitives, in Hitlist order (hitable.clj:15-26):
+ *     prim_kind[i]  RTMI_PRIM_SPHERE (hitable.clj:180) | RTMI_PRIM_UVSPHERE (:141) | RTMI_PRIM_MOVING (:224)
+ *     prim_geom[i*9 + 0..8] = center0.xyz, radius, center1.xyz, t0, t1   (static: center1 = center0, t0 = 0, t1 = 1)
+ *     prim_mat[i]   material index
+ *   materials (shader.clj):
+ *     mat_kind[m]   RTMI_MAT_LAMBERTIAN (:29) | RTMI_MAT_METAL (:46) | RTMI_MAT_DIELECTRIC (:76) | RTMI_MAT_DIFFUSE_LIGHT (:114)
+ *     mat_tex[m]    texture index of albedo / emission (-1 for dielectric)
+ *     mat_param[m]  fuzz (metal) | ri (dielectric) | 0
+ *   textures (texture.clj):
+ *     tex_kind[t]   RTMI_TEX_CONSTANT (:14) | RTMI_TEX_UVGRADIENT (:26) | RTMI_TEX_CHECKER (:44)
+ *     tex_param[t*12 + ..] = constant: color.rgb | gradient: co, cu, cv, cuv (4 x rgb) | checker: scale
+ *     tex_child[t*2 + 0..1] = checker tex0, tex1 (else -1)
+ *   camera (camera.clj):
+ *     cam_kind      RTMI_CAM_PINHOLE (:8) | RTMI_CAM_THINLENS (:35)
+ *     cam[24]       origin, lleft, horiz, vert, u, v, w (7 x xyz), aperture, t0, t1
+ */
+#ifndef RTMI_H
+#define RTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMI_OK 0
+#define RTMI_E_ARG (-1)         /* bad argument / malformed scene */
+#define RTMI_E_DEVICE (-2)      /* no usable gfx950 device, or a HIP call failed */
+#define RTMI_E_UNSUPPORTED (-3) /* record type / option not available on the GPU path */
+#define RTMI_E_NOMEM (-4)
+#define RTMI_E_STATE (-5)       /* handle used after destroy, wrong context, ... */
+
+enum { RTMI_PRIM_SPHERE = 0, RTMI_PRIM_UVSPHERE = 1, RTMI_PRIM_MOVING = 2 };
+enum { RTMI_MAT_LAMBERTIAN = 0, RTMI_MAT_METAL = 1, RTMI_MAT_DIELECTRIC = 2, RTMI_MAT_DIFFUSE_LIGHT = 3 };
+enum { RTMI_TEX_CONSTANT = 0, RTMI_TEX_UVGRADIENT = 1, RTMI_TEX_CHECKER = 2 };
+enum { RTMI_CAM_PINHOLE = 0, RTMI_CAM_THINLENS = 1 };
+enum { RTMI_F64 = 0, RTMI_F32 = 1 };             /* arithmetic the kernels compute in */
+enum { RTMI_ACCEL_FLAT = 0, RTMI_ACCEL_BVH = 1 }; /* Hitlist scan (hitable.clj:15-26) | bvh-node descent (hitable.clj:97-123) */
+
+#define RTMI_PRIM_STRIDE 9
+#define RTMI_TEX_STRIDE 12
+#define RTMI_TILE 8          /* framebuffer tiles are RTMI_TILE x RTMI_TILE pixels */
+#define RTMI_TILE_PIXELS 64
+#define RTMI_SEG_REC 12      /* doubles per logged path segment: prim, t, p.xyz, n.xyz, next dir.xyz, scattered? */
+
+#define RTMI_FLAG_TIMING 1u  /* record HIP events around the trace kernel (rtmi_last_trace_ms) */
+
+typedef struct rtmi_ctx rtmi_ctx;
+typedef struct rtmi_scene rtmi_scene;
+
+/* ---- library / context ---------------------------------------------------------------- */
+const char *rtmi_last_error(void);
+const char *rtmi_backend_name(void); /* "hip-gfx950" */
+int rtmi_version(void);
+
+/* Binds a context to HIP device `device` (one process per GPU: pass LOCAL_RANK). */
+int rtmi_init(int device, uint32_t flags, rtmi_ctx **out_ctx);
+int rtmi_shutdown(rtmi_ctx *ctx);
+/* knobs: "blocks_per_cu" (int), "workspace_bytes" (sample-buffer budget), "accel" (RTMI_ACCEL_*) */
+int rtmi_set_option(rtmi_ctx *ctx, const char *name, int64_t value);
+int rtmi_device_info(rtmi_ctx *ctx, int32_t *compute_units, int32_t *lds_bytes_per_cu, int64_t *hbm_bytes, char *arch, int32_t arch_len);
+
+/* ---- scene ------------------------------------------------------------------------------- */
+/* Replaces building the world the reference's Hitlist.hit? walks (hitable.clj:15-26) and the
+ * camera record get-ray reads (camera.clj:8-16,35-48): uploads the flat arrays to HBM (SoA). */
+int rtmi_scene_create(rtmi_ctx *ctx,
+                      int32_t n_prims, const int32_t *prim_kind, const double *prim_geom, const int32_t *prim_mat,
+                      int32_t n_mats, const int32_t *mat_kind, const int32_t *mat_tex, const double *mat_param,
+                      int32_t n_tex, const int32_t *tex_kind, const double *tex_param, const int32_t *tex_child,
+                      int32_t cam_kind, const double *cam, rtmi_scene **out_scene);
+int rtmi_scene_destroy(rtmi_scene *scene);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* Replaces core.clj:100-108 for the output region [x0,x1) x [y0,y1): for each pixel, ns jittered
+ * samples of `color` (core.clj:17-41, depth as core.clj:20,45), mean, gamma 2, 8-bit (core.clj:52-57).
+ * out_linear: (y1-y0)*(x1-x0)*3 doubles, the per-pixel mean BEFORE sqrt (for RMS parity), may be NULL;
+ * out_rgb8: same shape uint8, trunc(min(255.99, 255.99*sqrt(mean))), NaN -> 0, may be NULL;
+ * out_counters: {total-rays (core.clj:24), total-pixels (core.clj:47)} (metrics.clj:8-9), may be NULL.
+ * Every random draw is the next value of the counter stream keyed (seed, j*nx+i, sample). */
+int rtmi_render(rtmi_scene *scene, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed, int32_t precision,
+                int32_t x0, int32_t y0, int32_t x1, int32_t y1,
+                double *out_linear, uint8_t *out_rgb8, uint64_t *out_counters);
+
+/* Same path with every buffer resident in HBM (device pointers), launched on `stream` (a hipStream_t,
+ * NULL = the context's own stream); asynchronous.  d_out_linear holds doubles for both precisions. */
+int rtmi_render_device(rtmi_scene *scene, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed, int32_t precision,
+                       void *d_out_linear, void *d_out_rgb8, void *d_out_counters, void *stream);
+
+/* Tile-partitioned form for one-process-per-GPU rendering (the reference's tiled-coords,
+ * core.clj:59-71, becomes 8x8 tiles dealt round-robin): renders global tiles
+ * tile_first, tile_first+tile_stride, ... (row-major tile index over ceil(nx/8) x ceil(ny/8)) into
+ * d_tiles_linear[k][64][3] doubles (per-pixel mean, tile-major; pixels outside the image are 0).
+ * The number of local tiles is rtmi_local_tiles(nx, ny, tile_first, tile_stride). */
+int rtmi_render_tiles_device(rtmi_scene *scene, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed, int32_t precision,
+                             int32_t tile_first, int32_t tile_stride,
+                             void *d_tiles_linear, void *d_out_counters, void *stream);
+int32_t rtmi_local_tiles(int32_t nx, int32_t ny, int32_t tile_first, int32_t tile_stride);
+
+/* After the gather: d_gathered[r][k][64][3] (r < world, k < tiles_per_rank, rank r's k-th tile is global
+ * tile r + k*world) -> dense row-major frame (doubles, may be NULL) + 8-bit frame (may be NULL). */
+int rtmi_assemble_device(rtmi_ctx *ctx, int32_t nx, int32_t ny, int32_t world, int32_t tiles_per_rank,
+                         const void *d_gathered, void *d_out_linear, void *d_out_rgb8, void *stream);
+
+/* Total milliseconds of the trace-kernel launches of every render on this context since the previous call
+ * (HIP events recorded on the launch stream around each launch; needs RTMI_FLAG_TIMING; synchronises on the
+ * last event; at most 8192 launches are kept).  *launches = kernel launches covered.  Resets the window. */
+int rtmi_last_trace_ms(rtmi_ctx *ctx, double *ms, int32_t *launches);
+
+/* ---- probes: the same device functions the render kernel runs, one protocol call at a time ---- */
+/* Hitable.hit? of the world for n rays {o.xyz, d.xyz, time}; out[n][11] = hit?, prim, t, p.xyz, normal.xyz, u, v */
+int rtmi_probe_hit(rtmi_scene *scene, int32_t precision, int32_t n, const double *rays, double t_min, double t_max, double *out);
+/* `color` (core.clj:17-41) of n explicit rays with their own stream keys; log (may be NULL):
+ * [n][max_seg][RTMI_SEG_REC]; out_nlog[n] segments logged. */
+int rtmi_probe_paths(rtmi_scene *scene, int32_t precision, int32_t n, const double *rays, const uint64_t *keys, uint64_t ctr0,
+                     int32_t depth, double *out_rgb, uint64_t *out_nseg, double *log, int32_t max_seg, int32_t *out_nlog);
+/* Camera.get-ray for n (u,v) pairs; out[n][8] = o.xyz, d.xyz, time, draws consumed */
+int rtmi_probe_camera(rtmi_scene *scene, int32_t precision, int32_t n, const double *uv, const uint64_t *keys, double *out);
+/* Texture.sample of texture `tex` for n {u, v, p.xyz}; out[n][3] */
+int rtmi_probe_texture(rtmi_scene *scene, int32_t precision, int32_t tex, int32_t n, const double *uvp, double *out);
+/* Shader.scatter of material `mat` for n rays and hit records {p.xyz, normal.xyz, u, v};
+ * out[n][9] = scattered?, dir.xyz, attenuation.rgb, time, draws consumed */
+int rtmi_probe_scatter(rtmi_scene *scene, int32_t precision, int32_t mat, int32_t n, const double *rays, const double *hits,
+                       const uint64_t *keys, double *out);
+/* The counter stream: out_bits[k] = 64 raw bits, out_real[k] = the uniform in [0,1) for draw index d0+k of `key` */
+int rtmi_probe_rng(rtmi_ctx *ctx, int32_t precision, uint64_t key, uint64_t d0, int32_t n, uint64_t *out_bits, double *out_real);
+/* sample key of (seed, pixel index j*nx+i, sample) -- pure host function, no device needed */
+uint64_t rtmi_sample_key(uint64_t seed, uint64_t pixel, uint64_t sample);
+/* correctly-rounded device arithmetic check: out[k] = {a/b, sqrt(|a|), a*b+c unfused} */
+int rtmi_probe_arith(rtmi_ctx *ctx, int32_t n, const double *abc, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMI_H */

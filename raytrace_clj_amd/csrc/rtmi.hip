@@ -1,0 +1,938 @@
+// rtmi.hip -- kernels + C-ABI (include/rtmi.h) of the MI355X sampling path.  gfx950 only.
+//
+// Data flow of one render (all buffers in HBM):
+//   scene SoA (static spheres {cx,cy,cz,r} | moving spheres | material / texture tables)
+//     -> trace kernel: persistent 256-thread workgroups; the sphere SoA is staged into LDS as
+//        {cx,cy,cz,r*r}; every lane owns one path (sample) at a time and runs one `color` iteration
+//        (core.clj:17-41) per loop trip; lanes whose path ended are refilled from the workgroup's work
+//        list (wave ballot + popcount prefix sum -> one LDS atomic per wave), so the sphere scan always
+//        runs with full waves; a finished sample stores its colour at samples[tile][s][pixel]
+//     -> reduce kernel: per pixel, sum over s IN SAMPLE ORDER (core.clj:52 reduce mat/add), * 1/ns
+//     -> assemble kernel: tile-major -> dense frame, sqrt, *255.99, min, trunc (core.clj:54-56)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rtmi.h"
+#include "rtmi_device.h"
+
+using namespace rtmi;
+
+#define RTMI_EXPORT extern "C" __attribute__((visibility("default")))
+
+// =====================================================================================================
+// kernels
+// =====================================================================================================
+namespace {
+
+constexpr int kBlock = 256;
+
+struct TraceParams {
+    int nx, ny, depth;
+    u64 seed;
+    int tiles_x;
+    int n_local_tiles;
+    const int *tile_ids;   // [n_local_tiles] global tile index (row-major over tiles)
+    int s_begin, s_count;  // samples [s_begin, s_begin + s_count) of every pixel in this pass
+    void *samples;         // [n_local_tiles * s_count][64][3] real
+    u64 *counters;         // [0] += ray segments (metrics total-rays, core.clj:24)
+    int prims_per_tile;    // static spheres per LDS tile
+    int n_ptiles;          // number of LDS tiles the static spheres are cut into
+};
+
+// Stage static spheres [first, first+count) into LDS as {cx, cy, cz, r*r} (hitable.clj:188: (* radius radius)).
+template <typename R> __device__ inline void stage_prims(const DevScene &sc, Prim4<R> *lds, int first, int count) {
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        const double *g = sc.stat_geom + (size_t)(first + i) * 4;
+        Prim4<R> p;
+        p.cx = (R)g[0]; p.cy = (R)g[1]; p.cz = (R)g[2];
+        const R r = (R)g[3];
+        p.r2 = r * r;
+        lds[i] = p;
+    }
+}
+
+// hit? of the whole world for the lane's ray (closest hit, t in (0.001, Float/MAX_VALUE), core.clj:25).
+// MULTI: the static spheres do not fit one LDS tile; every thread of the workgroup must call this.
+template <typename R, bool MULTI>
+__device__ inline void intersect_world(const DevScene &sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, const Path<R> &P,
+                                       bool active, R tmin, R tmax, R &best_t, int &best_i) {
+    best_t = tmax;
+    best_i = -1;
+    const R a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
+    if (!MULTI) {
+        if (active) scan_static<R>(lds, sc.n_static, 0, P, a, tmin, best_t, best_i);
+    } else {
+        for (int tile = 0; tile < n_ptiles; ++tile) {
+            const int first = tile * prims_per_tile;
+            const int count = min(prims_per_tile, sc.n_static - first);
+            __syncthreads();
+            stage_prims<R>(sc, lds, first, count);
+            __syncthreads();
+            if (active) scan_static<R>(lds, count, first, P, a, tmin, best_t, best_i);
+        }
+    }
+    if (active && sc.n_moving > 0) {
+        int best_orig = best_i >= 0 ? sc.stat_orig[best_i] : 0x7fffffff;
+        scan_moving<R>(sc, P, a, tmin, best_t, best_i, best_orig);
+    }
+}
+
+// core.clj:43-51: jittered (u, v) for sample s of pixel (i, j), then the camera ray.
+template <typename R> __device__ inline void start_sample(const DevScene &sc, const TraceParams &tp, int i, int j, int s, Path<R> &P) {
+    P.key = sample_key(tp.seed, (u64)j * (u64)tp.nx + (u64)i, (u64)s);
+    P.ctr = 0;
+    const R u = ((R)(float)i + next_uniform(P)) / (R)tp.nx;
+    const R v = ((R)(float)j + next_uniform(P)) / (R)tp.ny;
+    get_ray<R>(sc, u, v, P);
+    P.ar = P.ag = P.ab = R(1);
+    P.cr = P.cg = P.cb = R(0);
+    P.depth = tp.depth;
+}
+
+template <typename R, bool MULTI>
+__global__ void __launch_bounds__(kBlock) trace_kernel(DevScene sc, TraceParams tp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Prim4<R> *lds = reinterpret_cast<Prim4<R> *>(smem);
+    unsigned *wg_next = reinterpret_cast<unsigned *>(smem + (size_t)tp.prims_per_tile * sizeof(Prim4<R>));
+
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) *wg_next = 0u;
+    if (!MULTI) stage_prims<R>(sc, lds, 0, sc.n_static);
+    __syncthreads();
+
+    // This workgroup's work list: chunks blockIdx.x, blockIdx.x + gridDim.x, ...; a chunk is one 8x8 pixel
+    // tile x one sample index (64 work items); chunk c -> (local tile c / s_count, sample s_begin + c % s_count).
+    const long long total_chunks = (long long)tp.n_local_tiles * tp.s_count;
+    const long long my_chunks = total_chunks > blockIdx.x ? (total_chunks - blockIdx.x - 1) / gridDim.x + 1 : 0;
+    const unsigned total_m = (unsigned)min(my_chunks * 64, (long long)0xffffff00u);
+
+    Path<R> P;
+    P.ox = P.oy = P.oz = P.dx = P.dy = P.dz = P.time = R(0);
+    P.ar = P.ag = P.ab = P.cr = P.cg = P.cb = R(0);
+    P.key = 0; P.ctr = 0; P.depth = 0;
+    bool alive = false;
+    bool exhausted = (total_m == 0);
+    size_t out_idx = 0;
+    unsigned nrays = 0;
+    const R tmin = R(0.001), tmax = Real<R>::tmax();
+
+    for (;;) {
+        // ---- refill dead lanes: ballot -> popcount prefix -> one LDS atomic per wave -------------------
+        while (!exhausted) {
+            const u64 dead = __ballot(!alive);
+            if (dead == 0) break;
+            const int cnt = __popcll(dead);
+            const int leader = __ffsll((long long)dead) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(wg_next, (unsigned)cnt);
+            base = __shfl(base, leader);
+            if (base >= total_m) { exhausted = true; break; }
+            if (base + (unsigned)cnt >= total_m) exhausted = true;
+            if (!alive) {
+                const unsigned m = base + (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
+                if (m < total_m) {
+                    const long long chunk = (long long)blockIdx.x + (long long)(m >> 6) * gridDim.x;
+                    const int l = (int)(m & 63u);
+                    const int tile_local = (int)(chunk / tp.s_count);
+                    const int s = tp.s_begin + (int)(chunk - (long long)tile_local * tp.s_count);
+                    const int gtile = tp.tile_ids[tile_local];
+                    const int x = (gtile % tp.tiles_x) * RTMI_TILE + (l & 7);
+                    const int y = (gtile / tp.tiles_x) * RTMI_TILE + (l >> 3);
+                    if (x < tp.nx && y < tp.ny) {
+                        start_sample<R>(sc, tp, x, tp.ny - 1 - y, s, P); // j = ny-1-y (core.clj:105)
+                        out_idx = ((size_t)chunk * 64 + (size_t)l) * 3;
+                        alive = true;
+                    }
+                }
+            }
+        }
+        if (MULTI) { if (!__syncthreads_or(alive ? 1 : 0)) break; }
+        else { if (!__any(alive ? 1 : 0)) break; }
+
+        // ---- one iteration of `color` for every live lane ---------------------------------------------
+        R best_t; int best_i;
+        intersect_world<R, MULTI>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i);
+        if (alive) {
+            ++nrays;
+            if (!shade_segment<R>(sc, P, best_t, best_i, nullptr)) {
+                R *out = reinterpret_cast<R *>(tp.samples) + out_idx;
+                out[0] = P.cr; out[1] = P.cg; out[2] = P.cb;
+                alive = false;
+            }
+        }
+    }
+    // total-rays: wave reduction, one atomic per wave
+    unsigned n = nrays;
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
+    if (lane == 0 && n) atomicAdd(tp.counters, (u64)n);
+}
+
+// core.clj:52-53: (reduce mat/add) over the samples IN ORDER, then (mul (/ 1.0 nr)) on the last pass.
+template <typename R>
+__global__ void __launch_bounds__(kBlock) reduce_kernel(const R *__restrict__ samples, R *__restrict__ accum, double *__restrict__ tiles_linear,
+                                                        const int *__restrict__ tile_ids, int tiles_x, int nx, int ny, int n_local_tiles,
+                                                        int s_begin, int s_count, int ns, u64 *counters, u64 n_valid_pixels) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid == 0 && counters && s_begin + s_count >= ns) counters[1] = n_valid_pixels; // metrics total-pixels, core.clj:47
+    if (gid >= (long long)n_local_tiles * 64) return;
+    const int tile_local = (int)(gid >> 6), l = (int)(gid & 63);
+    const int gtile = tile_ids[tile_local];
+    const int x = (gtile % tiles_x) * RTMI_TILE + (l & 7), y = (gtile / tiles_x) * RTMI_TILE + (l >> 3);
+    const bool valid = x < nx && y < ny;
+    R r = R(0), g = R(0), b = R(0);
+    if (valid) {
+        if (s_begin > 0) { r = accum[gid * 3]; g = accum[gid * 3 + 1]; b = accum[gid * 3 + 2]; }
+        for (int s = 0; s < s_count; ++s) {
+            const R *p = samples + (((size_t)tile_local * s_count + s) * 64 + l) * 3;
+            if (s_begin + s == 0) { r = p[0]; g = p[1]; b = p[2]; }
+            else { r = r + p[0]; g = g + p[1]; b = b + p[2]; }
+        }
+    }
+    if (s_begin + s_count < ns) {
+        accum[gid * 3] = r; accum[gid * 3 + 1] = g; accum[gid * 3 + 2] = b;
+    } else {
+        const R inv = R(1.0) / (R)ns;
+        tiles_linear[gid * 3] = valid ? (double)(r * inv) : 0.0;
+        tiles_linear[gid * 3 + 1] = valid ? (double)(g * inv) : 0.0;
+        tiles_linear[gid * 3 + 2] = valid ? (double)(b * inv) : 0.0;
+    }
+}
+
+// core.clj:54-56 + the y-flipped store of core.clj:105-106 (tiles already hold output rows).
+// gathered[r][k][64][3]: rank r's k-th tile is global tile r + k*world.
+template <typename R>
+__global__ void __launch_bounds__(kBlock) assemble_kernel(const double *__restrict__ gathered, int world, int tiles_per_rank, int tiles_x,
+                                                          int nx, int ny, double *__restrict__ out_linear, unsigned char *__restrict__ out_rgb8) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)nx * ny) return;
+    const int x = (int)(gid % nx), y = (int)(gid / nx);
+    const int gtile = (y / RTMI_TILE) * tiles_x + (x / RTMI_TILE);
+    const int r = gtile % world, k = gtile / world;
+    const int l = (y % RTMI_TILE) * RTMI_TILE + (x % RTMI_TILE);
+    const double *p = gathered + (((size_t)r * tiles_per_rank + k) * 64 + l) * 3;
+    for (int c = 0; c < 3; ++c) {
+        const double m = p[c];
+        if (out_linear) out_linear[gid * 3 + c] = m;
+        if (out_rgb8) {
+            const R q = Real<R>::sqrt_((R)m) * R(255.99);
+            // (int (min 255.99 q)): clojure.core/min propagates NaN and (int NaN) = 0
+            unsigned char o = 0;
+            if (q == q) { const R mq = q < R(255.99) ? q : R(255.99); o = (unsigned char)(int)mq; }
+            out_rgb8[gid * 3 + c] = o;
+        }
+    }
+}
+
+// ---- probe kernels (one protocol call per thread; same device functions as trace_kernel) -------------
+template <typename R> __device__ inline void load_ray(const double *q, Path<R> &P) {
+    P.ox = (R)q[0]; P.oy = (R)q[1]; P.oz = (R)q[2]; P.dx = (R)q[3]; P.dy = (R)q[4]; P.dz = (R)q[5]; P.time = (R)q[6];
+    P.ar = P.ag = P.ab = R(1); P.cr = P.cg = P.cb = R(0); P.key = 0; P.ctr = 0; P.depth = 0;
+}
+
+template <typename R>
+__global__ void __launch_bounds__(kBlock) probe_hit_kernel(DevScene sc, int prims_per_tile, int n_ptiles, int n, const double *rays, double tmin, double tmax, double *out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Prim4<R> *lds = reinterpret_cast<Prim4<R> *>(smem);
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = k < n;
+    Path<R> P;
+    load_ray<R>(rays + (size_t)(active ? k : 0) * 7, P);
+    R best_t; int best_i;
+    intersect_world<R, true>(sc, lds, prims_per_tile, n_ptiles, P, active, (R)tmin, (R)tmax, best_t, best_i);
+    if (!active) return;
+    double *o = out + (size_t)k * 11;
+    for (int c = 0; c < 11; ++c) o[c] = 0.0;
+    if (best_i < 0) return;
+    HitRec<R> h;
+    resolve_hit<R>(sc, P, best_t, best_i, h);
+    o[0] = 1.0; o[1] = h.orig; o[2] = h.t; o[3] = h.px; o[4] = h.py; o[5] = h.pz;
+    o[6] = h.nx; o[7] = h.ny; o[8] = h.nz; o[9] = h.u; o[10] = h.v;
+}
+
+template <typename R>
+__global__ void __launch_bounds__(kBlock) probe_paths_kernel(DevScene sc, int prims_per_tile, int n_ptiles, int n, const double *rays, const u64 *keys, u64 ctr0,
+                                                             int depth, double *out_rgb, u64 *out_nseg, double *log, int max_seg, int *out_nlog) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Prim4<R> *lds = reinterpret_cast<Prim4<R> *>(smem);
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    bool alive = k < n;
+    Path<R> P;
+    load_ray<R>(rays + (size_t)(alive ? k : 0) * 7, P);
+    P.key = alive ? keys[k] : 0; P.ctr = (unsigned)ctr0; P.depth = depth;
+    SegLog lg = {log ? log + (size_t)(alive ? k : 0) * max_seg * RTMI_SEG_REC : nullptr, max_seg, 0};
+    u64 nseg = 0;
+    const R tmin = R(0.001), tmax = Real<R>::tmax();
+    while (__syncthreads_or(alive ? 1 : 0)) {
+        R best_t; int best_i;
+        intersect_world<R, true>(sc, lds, prims_per_tile, n_ptiles, P, alive, tmin, tmax, best_t, best_i);
+        if (alive) {
+            ++nseg;
+            alive = shade_segment<R>(sc, P, best_t, best_i, log ? &lg : nullptr);
+        }
+    }
+    if (k < n) {
+        out_rgb[3 * k] = P.cr; out_rgb[3 * k + 1] = P.cg; out_rgb[3 * k + 2] = P.cb;
+        if (out_nseg) out_nseg[k] = nseg;
+        if (out_nlog) out_nlog[k] = lg.n;
+    }
+}
+
+template <typename R> __global__ void probe_camera_kernel(DevScene sc, int n, const double *uv, const u64 *keys, double *out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Path<R> P;
+    P.key = keys[k]; P.ctr = 0; P.depth = 0;
+    get_ray<R>(sc, (R)uv[2 * k], (R)uv[2 * k + 1], P);
+    double *o = out + (size_t)k * 8;
+    o[0] = P.ox; o[1] = P.oy; o[2] = P.oz; o[3] = P.dx; o[4] = P.dy; o[5] = P.dz; o[6] = P.time; o[7] = (double)P.ctr;
+}
+
+template <typename R> __global__ void probe_texture_kernel(DevScene sc, int tex, int n, const double *uvp, double *out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double *q = uvp + (size_t)k * 5;
+    R r, g, b;
+    tex_sample<R>(sc, tex, (R)q[0], (R)q[1], (R)q[2], (R)q[3], (R)q[4], r, g, b);
+    out[3 * k] = r; out[3 * k + 1] = g; out[3 * k + 2] = b;
+}
+
+// Shader.scatter (shader.clj) on an explicit hit record {p, normal, u, v}: the same scatter_emit the render kernel runs.
+template <typename R>
+__global__ void probe_scatter_kernel(DevScene sc, int mat, int n, const double *rays, const double *hits, const u64 *keys, double *out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Path<R> P;
+    load_ray<R>(rays + (size_t)k * 7, P);
+    P.key = keys[k]; P.ctr = 0; P.depth = 1;
+    const double *hq = hits + (size_t)k * 8;
+    HitRec<R> h;
+    h.t = R(0); h.px = (R)hq[0]; h.py = (R)hq[1]; h.pz = (R)hq[2]; h.nx = (R)hq[3]; h.ny = (R)hq[4]; h.nz = (R)hq[5];
+    h.u = (R)hq[6]; h.v = (R)hq[7]; h.orig = -1; h.kind = RTMI_PRIM_SPHERE; h.mat = mat;
+    R att[3] = {R(0), R(0), R(0)};
+    const bool scat = scatter_emit<R>(sc, P, h, att);
+    double *o = out + (size_t)k * 9;
+    o[0] = scat ? 1.0 : 0.0;
+    o[1] = scat ? P.dx : 0; o[2] = scat ? P.dy : 0; o[3] = scat ? P.dz : 0;
+    o[4] = scat ? att[0] : 0; o[5] = scat ? att[1] : 0; o[6] = scat ? att[2] : 0;
+    o[7] = scat ? P.time : 0; o[8] = (double)P.ctr;
+}
+
+template <typename R> __global__ void probe_rng_kernel(u64 key, u64 d0, int n, u64 *bits, double *real) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const u64 z = draw_bits(key, d0 + (u64)k);
+    bits[k] = z;
+    real[k] = (double)Real<R>::uniform(z);
+}
+
+__global__ void probe_arith_kernel(int n, const double *abc, double *out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double a = abc[3 * k], b = abc[3 * k + 1], c = abc[3 * k + 2];
+    out[3 * k] = a / b;
+    out[3 * k + 1] = ::sqrt(::fabs(a));
+    out[3 * k + 2] = a * b + c; // must stay unfused (-ffp-contract=off)
+}
+
+} // namespace
+
+// =====================================================================================================
+// host side: C-ABI
+// =====================================================================================================
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail(RTMI_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return RTMI_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (hipMalloc(&p, need) != hipSuccess) { p = nullptr; return fail(RTMI_E_NOMEM, "hipMalloc(%zu bytes) failed", need); }
+        bytes = need;
+        return RTMI_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+} // namespace
+
+struct rtmi_ctx {
+    uint32_t magic = 0x52544d49u;
+    int device = 0;
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    int cus = 0;
+    int lds_per_cu = 0;
+    size_t hbm = 0;
+    std::string arch;
+    int blocks_per_cu = 2;
+    int64_t workspace_bytes = (int64_t)8 << 30;
+    int accel = RTMI_ACCEL_FLAT;
+    int max_lds_bytes = 64 * 1024 - 64; // static-sphere LDS tile budget per workgroup
+    // workspace
+    DevBuf samples, accum, tiles, tile_ids, counters, scratch_lin;
+    std::vector<int> tile_ids_host;
+    int tile_key[4] = {-1, -1, -1, -1};
+    long long tile_valid_pixels = 0;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    int events_used = 0;
+};
+
+struct rtmi_scene {
+    uint32_t magic = 0x52545343u;
+    rtmi_ctx *ctx = nullptr;
+    DevScene dev{};
+    std::vector<void *> allocs;
+    int n_prims = 0, n_mats = 0, n_tex = 0;
+};
+
+namespace {
+
+bool ctx_ok(rtmi_ctx *c) { return c && c->magic == 0x52544d49u; }
+bool scene_ok(rtmi_scene *s) { return s && s->magic == 0x52545343u && ctx_ok(s->ctx); }
+
+template <typename T> int upload(rtmi_scene *s, const std::vector<T> &v, const T **out) {
+    void *p = nullptr;
+    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    if (hipMalloc(&p, bytes) != hipSuccess) return fail(RTMI_E_NOMEM, "hipMalloc(%zu) failed", bytes);
+    s->allocs.push_back(p);
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<const T *>(p);
+    return RTMI_OK;
+}
+
+// LDS tiling of the static spheres for a given precision
+void lds_plan(const rtmi_ctx *c, int n_static, size_t real_bytes, int *prims_per_tile, int *n_ptiles, size_t *lds_bytes) {
+    const size_t rec = 4 * real_bytes;
+    int cap = (int)((size_t)c->max_lds_bytes / rec);
+    int ppt = std::max(1, std::min(std::max(n_static, 1), cap));
+    *prims_per_tile = ppt;
+    *n_ptiles = std::max(1, (n_static + ppt - 1) / ppt);
+    *lds_bytes = (size_t)ppt * rec + 16;
+}
+
+int tiles_x_of(int nx) { return (nx + RTMI_TILE - 1) / RTMI_TILE; }
+int tiles_y_of(int ny) { return (ny + RTMI_TILE - 1) / RTMI_TILE; }
+
+int ensure_tile_ids(rtmi_ctx *c, int nx, int ny, int first, int stride, hipStream_t st, int *n_local) {
+    const int ntiles = tiles_x_of(nx) * tiles_y_of(ny);
+    const int nl = first < ntiles ? (ntiles - first - 1) / stride + 1 : 0;
+    *n_local = nl;
+    if (c->tile_key[0] == nx && c->tile_key[1] == ny && c->tile_key[2] == first && c->tile_key[3] == stride) return RTMI_OK;
+    c->tile_ids_host.resize((size_t)std::max(nl, 1));
+    const int tx_n = tiles_x_of(nx);
+    long long valid = 0;
+    for (int k = 0; k < nl; ++k) {
+        const int g = first + k * stride;
+        c->tile_ids_host[(size_t)k] = g;
+        const int w = std::min(RTMI_TILE, nx - (g % tx_n) * RTMI_TILE), h = std::min(RTMI_TILE, ny - (g / tx_n) * RTMI_TILE);
+        valid += (long long)w * h;
+    }
+    c->tile_valid_pixels = valid;
+    int rc = c->tile_ids.ensure((size_t)std::max(nl, 1) * sizeof(int));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->tile_ids.p, c->tile_ids_host.data(), (size_t)nl * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st)); // tile_ids_host may be rewritten by the next call
+    c->tile_key[0] = nx; c->tile_key[1] = ny; c->tile_key[2] = first; c->tile_key[3] = stride;
+    return RTMI_OK;
+}
+
+int next_event_pair(rtmi_ctx *c, hipEvent_t *a, hipEvent_t *b) {
+    if (c->events_used == (int)c->events.size()) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        c->events.emplace_back(e0, e1);
+    }
+    *a = c->events[(size_t)c->events_used].first;
+    *b = c->events[(size_t)c->events_used].second;
+    c->events_used++;
+    return RTMI_OK;
+}
+
+template <typename R>
+int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t seed, int first, int stride, void *d_tiles_linear,
+                      void *d_counters, hipStream_t st) {
+    rtmi_ctx *c = s->ctx;
+    int n_local = 0;
+    int rc = ensure_tile_ids(c, nx, ny, first, stride, st, &n_local);
+    if (rc) return rc;
+    if (d_counters) HIP_TRY(hipMemsetAsync(d_counters, 0, 2 * sizeof(u64), st));
+    if (n_local == 0) return RTMI_OK;
+    rc = c->counters.ensure(2 * sizeof(u64));
+    if (rc) return rc;
+    u64 *cnt = d_counters ? reinterpret_cast<u64 *>(d_counters) : reinterpret_cast<u64 *>(c->counters.p);
+
+    // sample-buffer passes: samples [s_begin, s_begin+s_count) of every local pixel per pass
+    const size_t per_sample = (size_t)n_local * 64 * 3 * sizeof(R);
+    int s_per_pass = (int)std::max<int64_t>(1, std::min<int64_t>(ns, c->workspace_bytes / (int64_t)per_sample));
+    const int grid_trace = std::max(1, c->cus * c->blocks_per_cu);
+    // a workgroup's work list is indexed with 32 bits: (chunks per workgroup) * 64 must stay below 2^32
+    while (s_per_pass > 1 && ((long long)n_local * s_per_pass / grid_trace + 1) * 64 >= 0xffffff00ll) s_per_pass /= 2;
+    rc = c->samples.ensure(per_sample * (size_t)s_per_pass);
+    if (rc) return rc;
+    if (s_per_pass < ns) {
+        rc = c->accum.ensure((size_t)n_local * 64 * 3 * sizeof(R));
+        if (rc) return rc;
+    }
+    int ppt, nptiles;
+    size_t lds_bytes;
+    lds_plan(c, s->dev.n_static, sizeof(R), &ppt, &nptiles, &lds_bytes);
+    const bool multi = nptiles > 1;
+
+    for (int s_begin = 0; s_begin < ns; s_begin += s_per_pass) {
+        const int s_count = std::min(s_per_pass, ns - s_begin);
+        TraceParams tp;
+        tp.nx = nx; tp.ny = ny; tp.depth = depth; tp.seed = seed; tp.tiles_x = tiles_x_of(nx);
+        tp.n_local_tiles = n_local; tp.tile_ids = reinterpret_cast<const int *>(c->tile_ids.p);
+        tp.s_begin = s_begin; tp.s_count = s_count; tp.samples = c->samples.p; tp.counters = cnt;
+        tp.prims_per_tile = ppt; tp.n_ptiles = nptiles;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if ((c->flags & RTMI_FLAG_TIMING) && c->events_used < 8192) {
+            rc = next_event_pair(c, &e0, &e1);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(e0, st));
+        }
+        if (multi) hipLaunchKernelGGL((trace_kernel<R, true>), dim3(grid_trace), dim3(kBlock), lds_bytes, st, s->dev, tp);
+        else hipLaunchKernelGGL((trace_kernel<R, false>), dim3(grid_trace), dim3(kBlock), lds_bytes, st, s->dev, tp);
+        HIP_TRY(hipGetLastError());
+        if (e1) HIP_TRY(hipEventRecord(e1, st));
+        const long long npx = (long long)n_local * 64;
+        hipLaunchKernelGGL((reduce_kernel<R>), dim3((unsigned)((npx + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           reinterpret_cast<const R *>(c->samples.p), reinterpret_cast<R *>(c->accum.p),
+                           reinterpret_cast<double *>(d_tiles_linear), reinterpret_cast<const int *>(c->tile_ids.p), tiles_x_of(nx), nx, ny,
+                           n_local, s_begin, s_count, ns, d_counters ? cnt : nullptr, (u64)c->tile_valid_pixels);
+        HIP_TRY(hipGetLastError());
+    }
+    return RTMI_OK;
+}
+
+int check_render_args(rtmi_scene *s, int nx, int ny, int ns, int depth, int precision) {
+    if (!scene_ok(s)) return fail(RTMI_E_STATE, "invalid scene handle");
+    if (nx <= 0 || ny <= 0 || ns <= 0 || depth < 0) return fail(RTMI_E_ARG, "nx, ny, ns must be > 0 and depth >= 0 (got %d %d %d %d)", nx, ny, ns, depth);
+    if ((long long)nx * ny > (1ll << 30)) return fail(RTMI_E_ARG, "frame too large");
+    if (precision != RTMI_F64 && precision != RTMI_F32) return fail(RTMI_E_ARG, "precision must be RTMI_F64 or RTMI_F32");
+    return RTMI_OK;
+}
+
+} // namespace
+
+// ---- library / context -------------------------------------------------------------------------------
+RTMI_EXPORT const char *rtmi_last_error(void) { return g_err.c_str(); }
+RTMI_EXPORT const char *rtmi_backend_name(void) { return "hip-gfx950"; }
+RTMI_EXPORT int rtmi_version(void) { return 100; }
+RTMI_EXPORT uint64_t rtmi_sample_key(uint64_t seed, uint64_t pixel, uint64_t sample) { return sample_key(seed, pixel, sample); }
+
+RTMI_EXPORT int rtmi_init(int device, uint32_t flags, rtmi_ctx **out_ctx) {
+    if (!out_ctx) return fail(RTMI_E_ARG, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RTMI_E_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(RTMI_E_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RTMI_E_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+    rtmi_ctx *c = new (std::nothrow) rtmi_ctx();
+    if (!c) return fail(RTMI_E_NOMEM, "out of host memory");
+    c->device = device;
+    c->flags = flags;
+    c->cus = prop.multiProcessorCount;
+    c->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    c->hbm = prop.totalGlobalMem;
+    c->arch = prop.gcnArchName;
+    if (const char *e = std::getenv("RTMI_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("RTMI_LDS_TILE_BYTES")) c->max_lds_bytes = std::min(64 * 1024 - 64, std::max(1024, std::atoi(e)));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(RTMI_E_DEVICE, "hipStreamCreate failed"); }
+    *out_ctx = c;
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_shutdown(rtmi_ctx *c) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->samples.release(); c->accum.release(); c->tiles.release(); c->tile_ids.release(); c->counters.release(); c->scratch_lin.release();
+    for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    (void)hipStreamDestroy(c->stream);
+    c->magic = 0;
+    delete c;
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_set_option(rtmi_ctx *c, const char *name, int64_t value) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (!name) return fail(RTMI_E_ARG, "name is NULL");
+    if (!std::strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 8) return fail(RTMI_E_ARG, "blocks_per_cu must be 1..8"); c->blocks_per_cu = (int)value; return RTMI_OK; }
+    if (!std::strcmp(name, "workspace_bytes")) { if (value < (1 << 20)) return fail(RTMI_E_ARG, "workspace_bytes must be >= 1 MiB"); c->workspace_bytes = value; return RTMI_OK; }
+    if (!std::strcmp(name, "lds_tile_bytes")) { if (value < 1024 || value > 64 * 1024 - 64) return fail(RTMI_E_ARG, "lds_tile_bytes out of range"); c->max_lds_bytes = (int)value; return RTMI_OK; }
+    if (!std::strcmp(name, "timing")) { if (value) c->flags |= RTMI_FLAG_TIMING; else c->flags &= ~RTMI_FLAG_TIMING; return RTMI_OK; }
+    if (!std::strcmp(name, "accel")) {
+        if (value == RTMI_ACCEL_FLAT) { c->accel = (int)value; return RTMI_OK; }
+        return fail(RTMI_E_UNSUPPORTED, "accel %lld is not available in this build", (long long)value);
+    }
+    return fail(RTMI_E_ARG, "unknown option '%s'", name);
+}
+
+RTMI_EXPORT int rtmi_device_info(rtmi_ctx *c, int32_t *cus, int32_t *lds, int64_t *hbm, char *arch, int32_t arch_len) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (cus) *cus = c->cus;
+    if (lds) *lds = c->lds_per_cu;
+    if (hbm) *hbm = (int64_t)c->hbm;
+    if (arch && arch_len > 0) { std::strncpy(arch, c->arch.c_str(), (size_t)arch_len - 1); arch[arch_len - 1] = 0; }
+    return RTMI_OK;
+}
+
+// ---- scene ---------------------------------------------------------------------------------------------
+RTMI_EXPORT int rtmi_scene_create(rtmi_ctx *c, int32_t n_prims, const int32_t *prim_kind, const double *prim_geom, const int32_t *prim_mat,
+                                  int32_t n_mats, const int32_t *mat_kind, const int32_t *mat_tex, const double *mat_param,
+                                  int32_t n_tex, const int32_t *tex_kind, const double *tex_param, const int32_t *tex_child,
+                                  int32_t cam_kind, const double *cam, rtmi_scene **out_scene) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (!out_scene) return fail(RTMI_E_ARG, "out_scene is NULL");
+    *out_scene = nullptr;
+    if (n_prims < 0 || n_mats < 0 || n_tex < 0) return fail(RTMI_E_ARG, "negative count");
+    if (n_prims > 0 && (!prim_kind || !prim_geom || !prim_mat)) return fail(RTMI_E_ARG, "primitive arrays are NULL");
+    if (n_mats > 0 && (!mat_kind || !mat_tex || !mat_param)) return fail(RTMI_E_ARG, "material arrays are NULL");
+    if (n_tex > 0 && (!tex_kind || !tex_param || !tex_child)) return fail(RTMI_E_ARG, "texture arrays are NULL");
+    if (!cam) return fail(RTMI_E_ARG, "cam is NULL");
+    if (cam_kind != RTMI_CAM_PINHOLE && cam_kind != RTMI_CAM_THINLENS) return fail(RTMI_E_UNSUPPORTED, "camera kind %d unsupported on GPU path", cam_kind);
+    // validate: this is where "unknown record type -> explicit unsupported error" surfaces
+    for (int t = 0; t < n_tex; ++t) {
+        if (tex_kind[t] < RTMI_TEX_CONSTANT || tex_kind[t] > RTMI_TEX_CHECKER) return fail(RTMI_E_UNSUPPORTED, "texture %d: kind %d unsupported on GPU path", t, tex_kind[t]);
+        if (tex_kind[t] == RTMI_TEX_CHECKER)
+            for (int k = 0; k < 2; ++k) {
+                const int ch = tex_child[2 * t + k];
+                if (ch < 0 || ch >= n_tex || ch == t) return fail(RTMI_E_ARG, "texture %d: checker child %d invalid", t, ch);
+            }
+    }
+    for (int m = 0; m < n_mats; ++m) {
+        if (mat_kind[m] < RTMI_MAT_LAMBERTIAN || mat_kind[m] > RTMI_MAT_DIFFUSE_LIGHT) return fail(RTMI_E_UNSUPPORTED, "material %d: kind %d unsupported on GPU path", m, mat_kind[m]);
+        if (mat_kind[m] != RTMI_MAT_DIELECTRIC && (mat_tex[m] < 0 || mat_tex[m] >= n_tex)) return fail(RTMI_E_ARG, "material %d: texture index %d invalid", m, mat_tex[m]);
+    }
+    std::vector<double> stat_geom, mov_geom;
+    std::vector<int> stat_orig, mov_orig, pk((size_t)n_prims), pm((size_t)n_prims);
+    for (int i = 0; i < n_prims; ++i) {
+        const int kind = prim_kind[i];
+        if (kind < RTMI_PRIM_SPHERE || kind > RTMI_PRIM_MOVING) return fail(RTMI_E_UNSUPPORTED, "primitive %d: kind %d unsupported on GPU path", i, kind);
+        if (prim_mat[i] < 0 || prim_mat[i] >= n_mats) return fail(RTMI_E_ARG, "primitive %d: material index %d invalid", i, prim_mat[i]);
+        pk[(size_t)i] = kind; pm[(size_t)i] = prim_mat[i];
+        const double *g = prim_geom + (size_t)i * RTMI_PRIM_STRIDE;
+        if (kind == RTMI_PRIM_MOVING) {
+            mov_geom.insert(mov_geom.end(), g, g + RTMI_PRIM_STRIDE);
+            mov_orig.push_back(i);
+        } else {
+            stat_geom.insert(stat_geom.end(), g, g + 4);
+            stat_orig.push_back(i);
+        }
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    rtmi_scene *s = new (std::nothrow) rtmi_scene();
+    if (!s) return fail(RTMI_E_NOMEM, "out of host memory");
+    s->ctx = c; s->n_prims = n_prims; s->n_mats = n_mats; s->n_tex = n_tex;
+    DevScene &d = s->dev;
+    d.n_static = (int)stat_orig.size(); d.n_moving = (int)mov_orig.size(); d.n_tex = n_tex; d.cam_kind = cam_kind;
+    std::memcpy(d.cam, cam, 24 * sizeof(double));
+    std::vector<int> mk(mat_kind, mat_kind + n_mats), mt(mat_tex, mat_tex + n_mats), tk(tex_kind, tex_kind + n_tex), tc(tex_child, tex_child + 2 * (size_t)n_tex);
+    std::vector<double> mp(mat_param, mat_param + n_mats), tpv(tex_param, tex_param + (size_t)n_tex * RTMI_TEX_STRIDE);
+    int rc = RTMI_OK;
+    if (!rc) rc = upload(s, stat_geom, &d.stat_geom);
+    if (!rc) rc = upload(s, stat_orig, &d.stat_orig);
+    if (!rc) rc = upload(s, mov_geom, &d.mov_geom);
+    if (!rc) rc = upload(s, mov_orig, &d.mov_orig);
+    if (!rc) rc = upload(s, pk, &d.prim_kind);
+    if (!rc) rc = upload(s, pm, &d.prim_mat);
+    if (!rc) rc = upload(s, mk, &d.mat_kind);
+    if (!rc) rc = upload(s, mt, &d.mat_tex);
+    if (!rc) rc = upload(s, mp, &d.mat_param);
+    if (!rc) rc = upload(s, tk, &d.tex_kind);
+    if (!rc) rc = upload(s, tpv, &d.tex_param);
+    if (!rc) rc = upload(s, tc, &d.tex_child);
+    if (rc) { rtmi_scene_destroy(s); return rc; }
+    *out_scene = s;
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_scene_destroy(rtmi_scene *s) {
+    if (!s || s->magic != 0x52545343u) return fail(RTMI_E_STATE, "invalid scene handle");
+    if (ctx_ok(s->ctx)) { (void)hipSetDevice(s->ctx->device); (void)hipStreamSynchronize(s->ctx->stream); }
+    for (void *p : s->allocs) (void)hipFree(p);
+    s->magic = 0;
+    delete s;
+    return RTMI_OK;
+}
+
+// ---- the hot path -------------------------------------------------------------------------------------
+RTMI_EXPORT int32_t rtmi_local_tiles(int32_t nx, int32_t ny, int32_t first, int32_t stride) {
+    if (nx <= 0 || ny <= 0 || first < 0 || stride <= 0) return 0;
+    const int ntiles = tiles_x_of(nx) * tiles_y_of(ny);
+    return first < ntiles ? (ntiles - first - 1) / stride + 1 : 0;
+}
+
+RTMI_EXPORT int rtmi_render_tiles_device(rtmi_scene *s, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed, int32_t precision,
+                                         int32_t tile_first, int32_t tile_stride, void *d_tiles_linear, void *d_out_counters, void *stream) {
+    int rc = check_render_args(s, nx, ny, ns, depth, precision);
+    if (rc) return rc;
+    if (tile_first < 0 || tile_stride <= 0) return fail(RTMI_E_ARG, "tile_first must be >= 0 and tile_stride > 0");
+    if (!d_tiles_linear) return fail(RTMI_E_ARG, "d_tiles_linear is NULL");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : s->ctx->stream;
+    if (precision == RTMI_F64) return render_tiles_impl<double>(s, nx, ny, ns, depth, seed, tile_first, tile_stride, d_tiles_linear, d_out_counters, st);
+    return render_tiles_impl<float>(s, nx, ny, ns, depth, seed, tile_first, tile_stride, d_tiles_linear, d_out_counters, st);
+}
+
+RTMI_EXPORT int rtmi_assemble_device(rtmi_ctx *c, int32_t nx, int32_t ny, int32_t world, int32_t tiles_per_rank, const void *d_gathered,
+                                     void *d_out_linear, void *d_out_rgb8, void *stream) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (nx <= 0 || ny <= 0 || world <= 0 || tiles_per_rank <= 0 || !d_gathered) return fail(RTMI_E_ARG, "bad assemble arguments");
+    const int ntiles = tiles_x_of(nx) * tiles_y_of(ny);
+    if ((long long)world * tiles_per_rank < ntiles) return fail(RTMI_E_ARG, "world*tiles_per_rank (%d*%d) does not cover %d tiles", world, tiles_per_rank, ntiles);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+    const long long npx = (long long)nx * ny;
+    // the 8-bit quantiser always runs in double on the double mean: both precisions share it
+    hipLaunchKernelGGL((assemble_kernel<double>), dim3((unsigned)((npx + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       reinterpret_cast<const double *>(d_gathered), world, tiles_per_rank, tiles_x_of(nx), nx, ny,
+                       reinterpret_cast<double *>(d_out_linear), reinterpret_cast<unsigned char *>(d_out_rgb8));
+    HIP_TRY(hipGetLastError());
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_render_device(rtmi_scene *s, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed, int32_t precision,
+                                   void *d_out_linear, void *d_out_rgb8, void *d_out_counters, void *stream) {
+    int rc = check_render_args(s, nx, ny, ns, depth, precision);
+    if (rc) return rc;
+    rtmi_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int ntiles = tiles_x_of(nx) * tiles_y_of(ny);
+    rc = c->tiles.ensure((size_t)ntiles * 64 * 3 * sizeof(double));
+    if (rc) return rc;
+    rc = rtmi_render_tiles_device(s, nx, ny, ns, depth, seed, precision, 0, 1, c->tiles.p, d_out_counters, stream);
+    if (rc) return rc;
+    if (!d_out_linear && !d_out_rgb8) return RTMI_OK;
+    return rtmi_assemble_device(c, nx, ny, 1, ntiles, c->tiles.p, d_out_linear, d_out_rgb8, stream);
+}
+
+RTMI_EXPORT int rtmi_render(rtmi_scene *s, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed, int32_t precision,
+                            int32_t x0, int32_t y0, int32_t x1, int32_t y1, double *out_linear, uint8_t *out_rgb8, uint64_t *out_counters) {
+    int rc = check_render_args(s, nx, ny, ns, depth, precision);
+    if (rc) return rc;
+    if (x0 < 0 || y0 < 0 || x1 > nx || y1 > ny || x1 <= x0 || y1 <= y0) return fail(RTMI_E_ARG, "region [%d,%d)x[%d,%d) outside %dx%d", x0, x1, y0, y1, nx, ny);
+    rtmi_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npx = (size_t)nx * ny;
+    // the host entry point renders the whole frame on the device and copies the region out
+    rc = c->scratch_lin.ensure(npx * 3 * sizeof(double) + npx * 3 + 2 * sizeof(u64) + 64);
+    if (rc) return rc;
+    char *base = reinterpret_cast<char *>(c->scratch_lin.p);
+    double *d_lin = reinterpret_cast<double *>(base);
+    u64 *d_cnt = reinterpret_cast<u64 *>(base + npx * 3 * sizeof(double));
+    unsigned char *d_q = reinterpret_cast<unsigned char *>(base + npx * 3 * sizeof(double) + 2 * sizeof(u64));
+    rc = rtmi_render_device(s, nx, ny, ns, depth, seed, precision, d_lin, d_q, d_cnt, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int w = x1 - x0, h = y1 - y0;
+    if (out_linear)
+        HIP_TRY(hipMemcpy2D(out_linear, (size_t)w * 3 * sizeof(double), d_lin + ((size_t)y0 * nx + x0) * 3, (size_t)nx * 3 * sizeof(double),
+                            (size_t)w * 3 * sizeof(double), (size_t)h, hipMemcpyDeviceToHost));
+    if (out_rgb8)
+        HIP_TRY(hipMemcpy2D(out_rgb8, (size_t)w * 3, d_q + ((size_t)y0 * nx + x0) * 3, (size_t)nx * 3, (size_t)w * 3, (size_t)h, hipMemcpyDeviceToHost));
+    if (out_counters) {
+        HIP_TRY(hipMemcpy(out_counters, d_cnt, 2 * sizeof(u64), hipMemcpyDeviceToHost));
+        out_counters[1] = (uint64_t)w * (uint64_t)h;
+    }
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_last_trace_ms(rtmi_ctx *c, double *ms, int32_t *launches) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (!(c->flags & RTMI_FLAG_TIMING)) return fail(RTMI_E_STATE, "context was not created with RTMI_FLAG_TIMING");
+    double total = 0.0;
+    for (int k = 0; k < c->events_used; ++k) {
+        HIP_TRY(hipEventSynchronize(c->events[(size_t)k].second));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, c->events[(size_t)k].first, c->events[(size_t)k].second));
+        total += t;
+    }
+    if (ms) *ms = total;
+    if (launches) *launches = c->events_used;
+    c->events_used = 0; // the next render starts a new measurement window
+    return RTMI_OK;
+}
+
+// ---- probes ---------------------------------------------------------------------------------------------
+namespace {
+struct Tmp { // scoped device temporaries for the (synchronous) probe entry points
+    std::vector<void *> ptrs;
+    ~Tmp() { for (void *p : ptrs) (void)hipFree(p); }
+    void *alloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr; ptrs.push_back(p); return p; }
+    void *up(const void *src, size_t bytes) { void *p = alloc(bytes); if (p && src && bytes) if (hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr; return p; }
+};
+#define PROBE_PROLOGUE(scene_)                                                             \
+    if (!scene_ok(scene_)) return fail(RTMI_E_STATE, "invalid scene handle");             \
+    if (precision != RTMI_F64 && precision != RTMI_F32) return fail(RTMI_E_ARG, "bad precision"); \
+    if (n < 0) return fail(RTMI_E_ARG, "n < 0");                                           \
+    if (n == 0) return RTMI_OK;                                                            \
+    rtmi_ctx *c = (scene_)->ctx;                                                           \
+    HIP_TRY(hipSetDevice(c->device));                                                      \
+    Tmp tmp;                                                                               \
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+#define PROBE_EPILOGUE()                      \
+    HIP_TRY(hipGetLastError());               \
+    HIP_TRY(hipStreamSynchronize(c->stream));
+} // namespace
+
+RTMI_EXPORT int rtmi_probe_hit(rtmi_scene *s, int32_t precision, int32_t n, const double *rays, double t_min, double t_max, double *out) {
+    PROBE_PROLOGUE(s)
+    if (!rays || !out) return fail(RTMI_E_ARG, "NULL array");
+    double *d_rays = (double *)tmp.up(rays, (size_t)n * 7 * sizeof(double));
+    double *d_out = (double *)tmp.alloc((size_t)n * 11 * sizeof(double));
+    if (!d_rays || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
+    int ppt, npt; size_t lds;
+    if (precision == RTMI_F64) {
+        lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
+        hipLaunchKernelGGL((probe_hit_kernel<double>), dim3(grid), dim3(kBlock), lds, c->stream, s->dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
+    } else {
+        lds_plan(c, s->dev.n_static, sizeof(float), &ppt, &npt, &lds);
+        hipLaunchKernelGGL((probe_hit_kernel<float>), dim3(grid), dim3(kBlock), lds, c->stream, s->dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
+    }
+    PROBE_EPILOGUE()
+    HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 11 * sizeof(double), hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_probe_paths(rtmi_scene *s, int32_t precision, int32_t n, const double *rays, const uint64_t *keys, uint64_t ctr0, int32_t depth,
+                                 double *out_rgb, uint64_t *out_nseg, double *log, int32_t max_seg, int32_t *out_nlog) {
+    PROBE_PROLOGUE(s)
+    if (!rays || !keys || !out_rgb) return fail(RTMI_E_ARG, "NULL array");
+    if (log && max_seg <= 0) return fail(RTMI_E_ARG, "log given but max_seg <= 0");
+    double *d_rays = (double *)tmp.up(rays, (size_t)n * 7 * sizeof(double));
+    u64 *d_keys = (u64 *)tmp.up(keys, (size_t)n * sizeof(u64));
+    double *d_rgb = (double *)tmp.alloc((size_t)n * 3 * sizeof(double));
+    u64 *d_nseg = (u64 *)tmp.alloc((size_t)n * sizeof(u64));
+    int *d_nlog = (int *)tmp.alloc((size_t)n * sizeof(int));
+    const size_t log_bytes = log ? (size_t)n * max_seg * RTMI_SEG_REC * sizeof(double) : 0;
+    double *d_log = log ? (double *)tmp.alloc(log_bytes) : nullptr;
+    if (!d_rays || !d_keys || !d_rgb || !d_nseg || !d_nlog || (log && !d_log)) return fail(RTMI_E_NOMEM, "probe buffers");
+    if (d_log) HIP_TRY(hipMemset(d_log, 0, log_bytes));
+    int ppt, npt; size_t lds;
+    if (precision == RTMI_F64) {
+        lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
+        hipLaunchKernelGGL((probe_paths_kernel<double>), dim3(grid), dim3(kBlock), lds, c->stream, s->dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
+    } else {
+        lds_plan(c, s->dev.n_static, sizeof(float), &ppt, &npt, &lds);
+        hipLaunchKernelGGL((probe_paths_kernel<float>), dim3(grid), dim3(kBlock), lds, c->stream, s->dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
+    }
+    PROBE_EPILOGUE()
+    HIP_TRY(hipMemcpy(out_rgb, d_rgb, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_nseg) HIP_TRY(hipMemcpy(out_nseg, d_nseg, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
+    if (out_nlog) HIP_TRY(hipMemcpy(out_nlog, d_nlog, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    if (log) HIP_TRY(hipMemcpy(log, d_log, log_bytes, hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_probe_camera(rtmi_scene *s, int32_t precision, int32_t n, const double *uv, const uint64_t *keys, double *out) {
+    PROBE_PROLOGUE(s)
+    if (!uv || !keys || !out) return fail(RTMI_E_ARG, "NULL array");
+    double *d_uv = (double *)tmp.up(uv, (size_t)n * 2 * sizeof(double));
+    u64 *d_keys = (u64 *)tmp.up(keys, (size_t)n * sizeof(u64));
+    double *d_out = (double *)tmp.alloc((size_t)n * 8 * sizeof(double));
+    if (!d_uv || !d_keys || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
+    if (precision == RTMI_F64) hipLaunchKernelGGL((probe_camera_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, s->dev, n, d_uv, d_keys, d_out);
+    else hipLaunchKernelGGL((probe_camera_kernel<float>), dim3(grid), dim3(kBlock), 0, c->stream, s->dev, n, d_uv, d_keys, d_out);
+    PROBE_EPILOGUE()
+    HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 8 * sizeof(double), hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_probe_texture(rtmi_scene *s, int32_t precision, int32_t tex, int32_t n, const double *uvp, double *out) {
+    PROBE_PROLOGUE(s)
+    if (!uvp || !out) return fail(RTMI_E_ARG, "NULL array");
+    if (tex < 0 || tex >= s->n_tex) return fail(RTMI_E_ARG, "texture index %d out of range", tex);
+    double *d_in = (double *)tmp.up(uvp, (size_t)n * 5 * sizeof(double));
+    double *d_out = (double *)tmp.alloc((size_t)n * 3 * sizeof(double));
+    if (!d_in || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
+    if (precision == RTMI_F64) hipLaunchKernelGGL((probe_texture_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, s->dev, tex, n, d_in, d_out);
+    else hipLaunchKernelGGL((probe_texture_kernel<float>), dim3(grid), dim3(kBlock), 0, c->stream, s->dev, tex, n, d_in, d_out);
+    PROBE_EPILOGUE()
+    HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_probe_scatter(rtmi_scene *s, int32_t precision, int32_t mat, int32_t n, const double *rays, const double *hits,
+                                   const uint64_t *keys, double *out) {
+    PROBE_PROLOGUE(s)
+    if (!rays || !hits || !keys || !out) return fail(RTMI_E_ARG, "NULL array");
+    if (mat < 0 || mat >= s->n_mats) return fail(RTMI_E_ARG, "material index %d out of range", mat);
+    double *d_rays = (double *)tmp.up(rays, (size_t)n * 7 * sizeof(double));
+    double *d_hits = (double *)tmp.up(hits, (size_t)n * 8 * sizeof(double));
+    u64 *d_keys = (u64 *)tmp.up(keys, (size_t)n * sizeof(u64));
+    double *d_out = (double *)tmp.alloc((size_t)n * 9 * sizeof(double));
+    if (!d_rays || !d_hits || !d_keys || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
+    if (precision == RTMI_F64) hipLaunchKernelGGL((probe_scatter_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, s->dev, mat, n, d_rays, d_hits, d_keys, d_out);
+    else hipLaunchKernelGGL((probe_scatter_kernel<float>), dim3(grid), dim3(kBlock), 0, c->stream, s->dev, mat, n, d_rays, d_hits, d_keys, d_out);
+    PROBE_EPILOGUE()
+    HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_probe_rng(rtmi_ctx *c, int32_t precision, uint64_t key, uint64_t d0, int32_t n, uint64_t *out_bits, double *out_real) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (precision != RTMI_F64 && precision != RTMI_F32) return fail(RTMI_E_ARG, "bad precision");
+    if (n <= 0 || !out_bits || !out_real) return fail(RTMI_E_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    Tmp tmp;
+    u64 *d_bits = (u64 *)tmp.alloc((size_t)n * sizeof(u64));
+    double *d_real = (double *)tmp.alloc((size_t)n * sizeof(double));
+    if (!d_bits || !d_real) return fail(RTMI_E_NOMEM, "probe buffers");
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    if (precision == RTMI_F64) hipLaunchKernelGGL((probe_rng_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, (u64)key, (u64)d0, n, d_bits, d_real);
+    else hipLaunchKernelGGL((probe_rng_kernel<float>), dim3(grid), dim3(kBlock), 0, c->stream, (u64)key, (u64)d0, n, d_bits, d_real);
+    PROBE_EPILOGUE()
+    HIP_TRY(hipMemcpy(out_bits, d_bits, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_real, d_real, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_probe_arith(rtmi_ctx *c, int32_t n, const double *abc, double *out) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (n <= 0 || !abc || !out) return fail(RTMI_E_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    Tmp tmp;
+    double *d_in = (double *)tmp.up(abc, (size_t)n * 3 * sizeof(double));
+    double *d_out = (double *)tmp.alloc((size_t)n * 3 * sizeof(double));
+    if (!d_in || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(probe_arith_kernel, dim3(grid), dim3(kBlock), 0, c->stream, n, d_in, d_out);
+    PROBE_EPILOGUE()
+    HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}

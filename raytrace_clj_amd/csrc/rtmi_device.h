@@ -1,0 +1,355 @@
+// rtmi_device.h -- device functions of the MI355X sampling path (gfx950 only, wave64).
+//
+// Every function states the reference lines it replaces (paths relative to the reference repo).
+// Arithmetic contract: this file is compiled with -ffp-contract=off; every + - * / sqrt below is one
+// correctly-rounded IEEE operation in the order the reference's core.matrix/vectorz calls perform
+// them (variadic add/mul = left fold, dot = (x0*y0 + x1*y1) + x2*y2, normalise = v * (1/|v|)), so
+// ray geometry is bit-reproducible against a CPU evaluation of the same formulas.  sin/asin/atan2/
+// pow only feed terminal colours and sign/probability tests, never the ray geometry.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rtmi.h"
+
+namespace rtmi {
+
+typedef unsigned long long u64;
+
+// ---- flat scene as the kernels see it (all pointers are HBM) -----------------------------------
+struct DevScene {
+    int n_static;            // Sphere + UVSphere records, original relative order
+    int n_moving;            // MovingSphere records
+    const double *stat_geom; // [n_static][4]  cx cy cz radius
+    const int *stat_orig;    // [n_static] index in the caller's Hitlist
+    const double *mov_geom;  // [n_moving][9]  c0.xyz radius c1.xyz t0 t1
+    const int *mov_orig;
+    const int *prim_kind;    // by original index
+    const int *prim_mat;
+    const int *mat_kind;
+    const int *mat_tex;
+    const double *mat_param;
+    int n_tex;
+    const int *tex_kind;
+    const double *tex_param; // [n_tex][12]
+    const int *tex_child;    // [n_tex][2]
+    int cam_kind;
+    double cam[24];          // kernarg -> SGPRs
+};
+
+// ---- counter-based stream: replaces clojure.core/rand (core.clj:49-50, util.clj:35-36,46-48,
+//      camera.clj:39,48, shader.clj:93); identical bits on host and device ------------------------
+#define RTMI_GOLD 0x9E3779B97F4A7C15ULL
+__host__ __device__ inline u64 mix64(u64 z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return z;
+}
+__host__ __device__ inline u64 sample_key(u64 seed, u64 pix, u64 s) {
+    return mix64(mix64(seed ^ (RTMI_GOLD * (pix + 1))) + 0xD1B54A32D192ED03ULL * (s + 1));
+}
+__host__ __device__ inline u64 draw_bits(u64 key, u64 d) { return mix64(key + RTMI_GOLD * (d + 1)); }
+
+template <typename R> struct Real;
+template <> struct Real<double> {
+    __device__ static inline double uniform(u64 z) { return (double)(z >> 11) * (1.0 / 9007199254740992.0); }
+    __device__ static inline double tmax() { return 3.4028234663852886e38; } // Float/MAX_VALUE, core.clj:25
+    __device__ static inline double pi() { return 3.141592653589793; }
+    __device__ static inline double sqrt_(double x) { return ::sqrt(x); }
+    __device__ static inline double sin_(double x) { return ::sin(x); }
+    __device__ static inline double asin_(double x) { return ::asin(x); }
+    __device__ static inline double atan2_(double y, double x) { return ::atan2(y, x); }
+    __device__ static inline double pow_(double x, double y) { return ::pow(x, y); }
+};
+template <> struct Real<float> {
+    __device__ static inline float uniform(u64 z) { return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f); }
+    __device__ static inline float tmax() { return 3.4028234663852886e38f; }
+    __device__ static inline float pi() { return 3.141592653589793f; }
+    __device__ static inline float sqrt_(float x) { return ::sqrtf(x); }
+    __device__ static inline float sin_(float x) { return ::sinf(x); }
+    __device__ static inline float asin_(float x) { return ::asinf(x); }
+    __device__ static inline float atan2_(float y, float x) { return ::atan2f(y, x); }
+    __device__ static inline float pow_(float x, float y) { return ::powf(x, y); }
+};
+
+// ---- per-path state: the loop/recur state of `color` (core.clj:23) plus the sample's stream -------
+template <typename R> struct Path {
+    R ox, oy, oz, dx, dy, dz, time; // ray map {:origin :direction :time}, util.clj:13-16
+    R ar, ag, ab;                   // atten
+    R cr, cg, cb;                   // accum
+    u64 key;
+    unsigned ctr;
+    int depth;
+};
+
+template <typename R> __device__ inline R next_uniform(Path<R> &P) { return Real<R>::uniform(draw_bits(P.key, P.ctr++)); }
+
+template <typename R> __device__ inline R dot3(R ax, R ay, R az, R bx, R by, R bz) { return (ax * bx + ay * by) + az * bz; }
+
+// util.clj:43-52 rand-in-unit-sphere (x, y, z drawn in that order; retry while p.p >= 1.0)
+template <typename R> __device__ inline void rand_in_unit_sphere(Path<R> &P, R &x, R &y, R &z) {
+    for (;;) {
+        x = R(2.0) * next_uniform(P) - R(1.0);
+        y = R(2.0) * next_uniform(P) - R(1.0);
+        z = R(2.0) * next_uniform(P) - R(1.0);
+        if (!(dot3(x, y, z, x, y, z) >= R(1.0))) return;
+    }
+}
+// util.clj:32-41 rand-in-unit-disk
+template <typename R> __device__ inline void rand_in_unit_disk(Path<R> &P, R &x, R &y) {
+    for (;;) {
+        x = R(2.0) * next_uniform(P) - R(1.0);
+        y = R(2.0) * next_uniform(P) - R(1.0);
+        if (!(dot3(x, y, R(0), x, y, R(0)) >= R(1.0))) return;
+    }
+}
+
+// camera.clj:8-16 (PinholeCamera.get-ray) and camera.clj:35-48 (ThinLensCamera.get-ray)
+template <typename R> __device__ inline void get_ray(const DevScene &sc, R s, R t, Path<R> &P) {
+    const double *c = sc.cam;
+    const R ox = (R)c[0], oy = (R)c[1], oz = (R)c[2];
+    // (add lleft (mul s horiz) (mul t vert) (negate origin) ...): left fold
+    R dx = (((R)c[3] + (R)c[6] * s) + (R)c[9] * t) + (-ox);
+    R dy = (((R)c[4] + (R)c[7] * s) + (R)c[10] * t) + (-oy);
+    R dz = (((R)c[5] + (R)c[8] * s) + (R)c[11] * t) + (-oz);
+    if (sc.cam_kind == RTMI_CAM_PINHOLE) {
+        P.ox = ox; P.oy = oy; P.oz = oz; P.dx = dx; P.dy = dy; P.dz = dz; P.time = R(0);
+        return;
+    }
+    const R lens_radius = (R)c[21] / R(2.0);
+    R rx, ry;
+    rand_in_unit_disk(P, rx, ry); // consumed even when aperture = 0
+    rx = lens_radius * rx; ry = lens_radius * ry;
+    const R offx = (R)c[12] * rx + (R)c[15] * ry;
+    const R offy = (R)c[13] * rx + (R)c[16] * ry;
+    const R offz = (R)c[14] * rx + (R)c[17] * ry;
+    P.ox = ox + offx; P.oy = oy + offy; P.oz = oz + offz;
+    P.dx = dx + (-offx); P.dy = dy + (-offy); P.dz = dz + (-offz);
+    const R t0 = (R)c[22], t1 = (R)c[23];
+    P.time = t0 + (t1 - t0) * next_uniform(P);
+}
+
+// texture.clj:14-16, 26-34, 44-50 (Texture.sample); checker children are walked iteratively
+template <typename R> __device__ inline void tex_sample(const DevScene &sc, int t, R u, R v, R px, R py, R pz, R &r, R &g, R &b) {
+    r = g = b = R(0);
+    for (int guard = 0; guard <= sc.n_tex; ++guard) {
+        const double *tp = sc.tex_param + (size_t)t * RTMI_TEX_STRIDE;
+        const int kind = sc.tex_kind[t];
+        if (kind == RTMI_TEX_CONSTANT) {
+            r = (R)tp[0]; g = (R)tp[1]; b = (R)tp[2];
+            return;
+        }
+        if (kind == RTMI_TEX_UVGRADIENT) {
+            const R omu = R(1.0) - u, omv = R(1.0) - v;
+            // a = cu*(1-u) + co*u ; b = cuv*(1-u) + cv*u ; out = b*(1-v) + a*v
+            const R a0 = (R)tp[3] * omu + (R)tp[0] * u, a1 = (R)tp[4] * omu + (R)tp[1] * u, a2 = (R)tp[5] * omu + (R)tp[2] * u;
+            const R b0 = (R)tp[9] * omu + (R)tp[6] * u, b1 = (R)tp[10] * omu + (R)tp[7] * u, b2 = (R)tp[11] * omu + (R)tp[8] * u;
+            r = b0 * omv + a0 * v; g = b1 * omv + a1 * v; b = b2 * omv + a2 * v;
+            return;
+        }
+        if (kind == RTMI_TEX_CHECKER) {
+            const R scale = (R)tp[0];
+            const R sines = (Real<R>::sin_(scale * px) * Real<R>::sin_(scale * py)) * Real<R>::sin_(scale * pz);
+            t = (sines < R(0)) ? sc.tex_child[2 * t] : sc.tex_child[2 * t + 1];
+            continue;
+        }
+        return;
+    }
+}
+
+// ---- geometry in LDS: {cx, cy, cz, r*r} per static sphere, broadcast-read by the whole wave ---------
+template <typename R> struct alignas(16) Prim4 { R cx, cy, cz, r2; };
+
+// hitable.clj:180-207 (Sphere.hit?) x hitable.clj:15-26 (Hitlist reduce), closest-hit form:
+// only (t, index) is kept per lane; p / normal / uv are rebuilt once for the winner.
+// `ok` uses strict comparisons on both ends (hitable.clj:195,203); the running t-max is the best t
+// so far (hitable.clj:20), so among equal t the first item in list order wins.
+template <typename R>
+__device__ inline void scan_static(const Prim4<R> *__restrict__ lds, int n, int idx_base, const Path<R> &P, R a, R tmin, R &best_t, int &best_i) {
+    const R a2 = R(2.0) * a, a4 = R(4.0) * a;
+#pragma unroll 2
+    for (int i = 0; i < n; ++i) {
+        const Prim4<R> s = lds[i];
+        const R ocx = P.ox - s.cx, ocy = P.oy - s.cy, ocz = P.oz - s.cz;
+        const R b = R(2.0) * dot3(ocx, ocy, ocz, P.dx, P.dy, P.dz);
+        const R c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - s.r2;
+        const R disc = b * b - a4 * c;
+        if (disc >= R(0)) {
+            const R sq = Real<R>::sqrt_(disc);
+            R t = (-b - sq) / a2;
+            bool ok = (t > tmin) && (t < best_t);
+            if (!ok) {
+                t = (-b + sq) / a2;
+                ok = (t > tmin) && (t < best_t);
+            }
+            if (ok) { best_t = t; best_i = idx_base + i; }
+        }
+    }
+}
+
+// hitable.clj:219-252 (MovingSphere.hit?): centre = lerp(c0, c1, (time-t0)/(t1-t0)) per ray.
+// Moving spheres are scanned after the static ones, so ties are resolved by original index.
+template <typename R>
+__device__ inline void scan_moving(const DevScene &sc, const Path<R> &P, R a, R tmin, R &best_t, int &best_i, int &best_orig) {
+    const R a2 = R(2.0) * a, a4 = R(4.0) * a;
+    for (int m = 0; m < sc.n_moving; ++m) {
+        const double *g = sc.mov_geom + (size_t)m * RTMI_PRIM_STRIDE;
+        const R t0 = (R)g[7], t1 = (R)g[8];
+        const R f = (P.time - t0) / (t1 - t0), omf = R(1.0) - f;
+        const R cx = (R)g[0] * omf + (R)g[4] * f, cy = (R)g[1] * omf + (R)g[5] * f, cz = (R)g[2] * omf + (R)g[6] * f;
+        const R rad = (R)g[3];
+        const R ocx = P.ox - cx, ocy = P.oy - cy, ocz = P.oz - cz;
+        const R b = R(2.0) * dot3(ocx, ocy, ocz, P.dx, P.dy, P.dz);
+        const R c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - rad * rad;
+        const R disc = b * b - a4 * c;
+        if (disc >= R(0)) {
+            const R sq = Real<R>::sqrt_(disc);
+            const int orig = sc.mov_orig[m];
+            R t = (-b - sq) / a2;
+            bool ok = (t > tmin) && ((t < best_t) || (t == best_t && orig < best_orig));
+            if (!ok) {
+                t = (-b + sq) / a2;
+                ok = (t > tmin) && ((t < best_t) || (t == best_t && orig < best_orig));
+            }
+            if (ok) { best_t = t; best_i = sc.n_static + m; best_orig = orig; }
+        }
+    }
+}
+
+// optional per-segment record for the parity probes (layout RTMI_SEG_REC)
+struct SegLog { double *rec; int max_seg; int n; };
+
+// the hit record {:t :p :uv :normal :material} (hitable.clj:196-199) of the winning primitive
+template <typename R> struct HitRec { R t, px, py, pz, nx, ny, nz, u, v; int orig, kind, mat; };
+
+// Rebuild the hit record of scan index best_i at parameter t: centre (hitable.clj:219-222 for moving
+// spheres), p = point-at-parameter (util.clj:18-22), normal = normalise(p - centre) (hitable.clj:194),
+// uv = get-sphere-uv for UVSphere (hitable.clj:128-139) else [0 0].
+template <typename R> __device__ inline void resolve_hit(const DevScene &sc, const Path<R> &P, R t, int best_i, HitRec<R> &h) {
+    R cx, cy, cz;
+    if (best_i < sc.n_static) {
+        const double *g = sc.stat_geom + (size_t)best_i * 4;
+        cx = (R)g[0]; cy = (R)g[1]; cz = (R)g[2];
+        h.orig = sc.stat_orig[best_i];
+    } else {
+        const int m = best_i - sc.n_static;
+        const double *g = sc.mov_geom + (size_t)m * RTMI_PRIM_STRIDE;
+        const R t0 = (R)g[7], t1 = (R)g[8];
+        const R f = (P.time - t0) / (t1 - t0), omf = R(1.0) - f;
+        cx = (R)g[0] * omf + (R)g[4] * f; cy = (R)g[1] * omf + (R)g[5] * f; cz = (R)g[2] * omf + (R)g[6] * f;
+        h.orig = sc.mov_orig[m];
+    }
+    h.kind = sc.prim_kind[h.orig];
+    h.mat = sc.prim_mat[h.orig];
+    h.t = t;
+    h.px = P.dx * t + P.ox; h.py = P.dy * t + P.oy; h.pz = P.dz * t + P.oz;
+    R nx = h.px - cx, ny = h.py - cy, nz = h.pz - cz;
+    const R len = Real<R>::sqrt_(dot3(nx, ny, nz, nx, ny, nz));
+    if (len > R(0)) { const R inv = R(1.0) / len; nx = nx * inv; ny = ny * inv; nz = nz * inv; }
+    h.nx = nx; h.ny = ny; h.nz = nz;
+    h.u = R(0); h.v = R(0);
+    if (h.kind == RTMI_PRIM_UVSPHERE) {
+        const R PI = Real<R>::pi();
+        const R phi = Real<R>::atan2_(nz, nx);
+        const R theta = Real<R>::asin_(ny);
+        h.u = R(1.0) - (phi + PI) / (R(2.0) * PI);
+        h.v = (theta + PI / R(2.0)) / PI;
+    }
+}
+
+// Shader.scatter + Shader.emitted for the hit record, and the atten/accum update of core.clj:27-39.
+// Returns true when the path continues (the `recur` of core.clj:30) with P holding the scattered ray.
+// `att` (optional) receives the attenuation of a successful scatter.
+template <typename R> __device__ inline bool scatter_emit(const DevScene &sc, Path<R> &P, const HitRec<R> &h, R *att) {
+    const int mat = h.mat;
+    const int mk = sc.mat_kind[mat];
+    const R px = h.px, py = h.py, pz = h.pz, nx = h.nx, ny = h.ny, nz = h.nz;
+    bool scat = false;
+    R sdx = R(0), sdy = R(0), sdz = R(0); // scattered direction
+    R atr = R(1), atg = R(1), atb = R(1);  // attenuation
+    if (mk == RTMI_MAT_DIFFUSE_LIGHT) { // shader.clj:114-119: scatter nil, emitted = sample
+        R er, eg, eb;
+        tex_sample(sc, sc.mat_tex[mat], h.u, h.v, px, py, pz, er, eg, eb);
+        P.cr = P.cr + P.ar * er; P.cg = P.cg + P.ag * eg; P.cb = P.cb + P.ab * eb; // core.clj:37-39
+    } else if (P.depth > 0) { // core.clj:27: (and (pos? depth) (scatter ...))
+        if (mk == RTMI_MAT_LAMBERTIAN) { // shader.clj:29-34
+            R rx, ry, rz;
+            rand_in_unit_sphere(P, rx, ry, rz);
+            const R tx = (px + nx) + rx, ty = (py + ny) + ry, tz = (pz + nz) + rz;
+            sdx = tx - px; sdy = ty - py; sdz = tz - pz;
+            tex_sample(sc, sc.mat_tex[mat], h.u, h.v, px, py, pz, atr, atg, atb);
+            scat = true;
+        } else if (mk == RTMI_MAT_METAL) { // shader.clj:46-57 + reflect shader.clj:6-9
+            const R fuzz = (R)sc.mat_param[mat];
+            R vx = P.dx, vy = P.dy, vz = P.dz;
+            {
+                const R len = Real<R>::sqrt_(dot3(vx, vy, vz, vx, vy, vz));
+                if (len > R(0)) { const R inv = R(1.0) / len; vx = vx * inv; vy = vy * inv; vz = vz * inv; }
+            }
+            const R k = R(2.0) * dot3(vx, vy, vz, nx, ny, nz);
+            const R rfx = vx - k * nx, rfy = vy - k * ny, rfz = vz - k * nz;
+            R rx, ry, rz;
+            rand_in_unit_sphere(P, rx, ry, rz); // drawn even when fuzz = 0
+            sdx = rfx + fuzz * rx; sdy = rfy + fuzz * ry; sdz = rfz + fuzz * rz;
+            if (dot3(sdx, sdy, sdz, nx, ny, nz) > R(0)) {
+                tex_sample(sc, sc.mat_tex[mat], h.u, h.v, px, py, pz, atr, atg, atb);
+                scat = true;
+            }
+        } else if (mk == RTMI_MAT_DIELECTRIC) { // shader.clj:76-102, refract 11-20, schlick 69-74
+            const R ri = (R)sc.mat_param[mat];
+            const R dn = dot3(P.dx, P.dy, P.dz, nx, ny, nz);
+            const R dmag = Real<R>::sqrt_(dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz));
+            R onx, ony, onz, eta, cosine;
+            if (dn > R(0)) { onx = -nx; ony = -ny; onz = -nz; eta = ri; cosine = ri * (dn / dmag); }
+            else { onx = nx; ony = ny; onz = nz; eta = R(1.0) / ri; cosine = -(dn / dmag); }
+            // refract: uv = normalise(d); dt = uv.n; disc = 1 - eta*eta*(1 - dt*dt)
+            R ux = P.dx, uy = P.dy, uz = P.dz;
+            if (dmag > R(0)) { const R inv = R(1.0) / dmag; ux = ux * inv; uy = uy * inv; uz = uz * inv; }
+            const R dt = dot3(ux, uy, uz, onx, ony, onz);
+            const R disc = R(1.0) - (eta * eta) * (R(1.0) - dt * dt);
+            // reflect(ray-direction, normal): un-normalised d, original normal
+            const R k = R(2.0) * dn;
+            const R rfx = P.dx - k * nx, rfy = P.dy - k * ny, rfz = P.dz - k * nz;
+            if (disc > R(0)) {
+                const R sq = Real<R>::sqrt_(disc);
+                const R rrx = eta * (ux - onx * dt) - onx * sq;
+                const R rry = eta * (uy - ony * dt) - ony * sq;
+                const R rrz = eta * (uz - onz * dt) - onz * sq;
+                R r0 = (R(1.0) - ri) / (R(1.0) + ri);
+                r0 = r0 * r0;
+                const R prob = r0 + (R(1.0) - r0) * Real<R>::pow_(R(1.0) - cosine, R(5.0));
+                if (next_uniform(P) < prob) { sdx = rfx; sdy = rfy; sdz = rfz; } // one draw, only when refraction is possible
+                else { sdx = rrx; sdy = rry; sdz = rrz; }
+            } else {
+                sdx = rfx; sdy = rfy; sdz = rfz;
+            }
+            scat = true;
+        }
+    }
+    if (!scat) return false;
+    if (att) { att[0] = atr; att[1] = atg; att[2] = atb; }
+    // recur: scattered ray (time inherited), depth-1, atten*attenuation; accum unchanged (emitted of these is 0)
+    P.ox = px; P.oy = py; P.oz = pz; P.dx = sdx; P.dy = sdy; P.dz = sdz;
+    P.ar = P.ar * atr; P.ag = P.ag * atg; P.ab = P.ab * atb;
+    P.depth -= 1;
+    return true;
+}
+
+// One iteration of `color`'s loop after hit? has returned (core.clj:25-41).
+template <typename R>
+__device__ inline bool shade_segment(const DevScene &sc, Path<R> &P, R t, int best_i, SegLog *lg) {
+    if (best_i < 0) return false; // miss: (color) returns accum, core.clj:40-41
+    HitRec<R> h;
+    resolve_hit<R>(sc, P, t, best_i, h);
+    const bool scat = scatter_emit<R>(sc, P, h, nullptr);
+    if (lg && lg->n < lg->max_seg) {
+        double *q = lg->rec + (size_t)lg->n * RTMI_SEG_REC;
+        q[0] = h.orig; q[1] = h.t; q[2] = h.px; q[3] = h.py; q[4] = h.pz; q[5] = h.nx; q[6] = h.ny; q[7] = h.nz;
+        q[8] = scat ? P.dx : 0; q[9] = scat ? P.dy : 0; q[10] = scat ? P.dz : 0; q[11] = scat ? 1.0 : 0.0;
+        lg->n++;
+    }
+    return scat;
+}
+
+} // namespace rtmi

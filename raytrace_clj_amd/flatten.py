@@ -1,0 +1,154 @@
+"""The flattener: walks a {:camera :world} scene built from the reference's record types and produces
+the flat arrays librtmi.so takes (layout: include/rtmi.h).
+
+World traversal: Hitlist (hitable.clj:15-26) in item order; bvh-node (hitable.clj:97-123) left then
+right, de-duplicating leaves by identity (a one-item make-bvh stores the same child twice,
+hitable.clj:113-114).  The closest hit of a bvh-node tree equals the closest hit of the flat list
+(both children are always visited with the un-narrowed interval, hitable.clj:100-105), so the device
+scans the flat list.  Anything that is not one of the mirrored records raises UnsupportedOnGpuPath so a
+caller can fall back to its own CPU path."""
+import numpy as np
+
+from . import camera as cam
+from . import hitable as hit
+from . import shader as shad
+from . import texture as tex
+
+PRIM_SPHERE, PRIM_UVSPHERE, PRIM_MOVING = 0, 1, 2
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
+TEX_CONSTANT, TEX_UVGRADIENT, TEX_CHECKER = 0, 1, 2
+CAM_PINHOLE, CAM_THINLENS = 0, 1
+PRIM_STRIDE, TEX_STRIDE = 9, 12
+
+
+class UnsupportedOnGpuPath(TypeError):
+    """A record type the GPU path does not implement (rectangles, boxes, instances, media, ...)."""
+
+
+class FlatScene:
+    """Flat SoA description of a scene.  Attributes are numpy arrays in the layout of include/rtmi.h."""
+
+    def __init__(self):
+        self.prim_kind = np.zeros(0, np.int32)
+        self.prim_geom = np.zeros((0, PRIM_STRIDE), np.float64)
+        self.prim_mat = np.zeros(0, np.int32)
+        self.mat_kind = np.zeros(0, np.int32)
+        self.mat_tex = np.zeros(0, np.int32)
+        self.mat_param = np.zeros(0, np.float64)
+        self.tex_kind = np.zeros(0, np.int32)
+        self.tex_param = np.zeros((0, TEX_STRIDE), np.float64)
+        self.tex_child = np.zeros((0, 2), np.int32)
+        self.cam_kind = CAM_PINHOLE
+        self.cam = np.zeros(24, np.float64)
+
+    @property
+    def n_prims(self):
+        return len(self.prim_kind)
+
+
+def _leaves(world, out, seen):
+    if isinstance(world, hit.Hitlist):
+        for it in world.items:
+            _leaves(it, out, seen)
+    elif isinstance(world, hit.bvh_node):
+        _leaves(world.left, out, seen)
+        _leaves(world.right, out, seen)
+    elif isinstance(world, (hit.Sphere, hit.UVSphere, hit.MovingSphere)):
+        if id(world) not in seen:
+            seen.add(id(world))
+            out.append(world)
+    elif isinstance(world, (list, tuple)):
+        for it in world:
+            _leaves(it, out, seen)
+    else:
+        raise UnsupportedOnGpuPath("%s is not supported on the GPU path" % type(world).__name__)
+
+
+class _Interner:
+    def __init__(self):
+        self.ids = {}
+        self.rows = []
+
+    def get(self, obj, build):
+        k = id(obj)
+        if k not in self.ids:
+            row = build(obj)            # children first, so a checker's children have lower ids
+            self.ids[k] = len(self.rows)
+            self.rows.append(row)
+        return self.ids[k]
+
+
+def flatten(scene_or_world, camera=None):
+    """flatten({"camera": c, "world": w}) or flatten(world, camera) -> FlatScene"""
+    if isinstance(scene_or_world, dict):
+        world, camera = scene_or_world["world"], scene_or_world["camera"]
+    else:
+        world = scene_or_world
+    leaves = []
+    _leaves(world, leaves, set())
+
+    textures, materials = _Interner(), _Interner()
+
+    def build_tex(t):
+        p = np.zeros(TEX_STRIDE)
+        if isinstance(t, tex.Constant):
+            p[0:3] = t.color
+            return (TEX_CONSTANT, p, (-1, -1))
+        if isinstance(t, tex.UVGradient):
+            p[0:3], p[3:6], p[6:9], p[9:12] = t.co, t.cu, t.cv, t.cuv
+            return (TEX_UVGRADIENT, p, (-1, -1))
+        if isinstance(t, tex.Checkerboard):
+            c0 = textures.get(t.tex0, build_tex)
+            c1 = textures.get(t.tex1, build_tex)
+            p[0] = t.scale
+            return (TEX_CHECKER, p, (c0, c1))
+        raise UnsupportedOnGpuPath("texture %s is not supported on the GPU path" % type(t).__name__)
+
+    def build_mat(m):
+        if isinstance(m, shad.Lambertian):
+            return (MAT_LAMBERTIAN, textures.get(m.albedo, build_tex), 0.0)
+        if isinstance(m, shad.Metal):
+            return (MAT_METAL, textures.get(m.albedo, build_tex), m.fuzz)
+        if isinstance(m, shad.Dielectric):
+            return (MAT_DIELECTRIC, -1, m.ri)
+        if isinstance(m, shad.DiffuseLight):
+            return (MAT_DIFFUSE_LIGHT, textures.get(m.tex, build_tex), 0.0)
+        raise UnsupportedOnGpuPath("material %s is not supported on the GPU path" % type(m).__name__)
+
+    fs = FlatScene()
+    n = len(leaves)
+    fs.prim_kind = np.zeros(n, np.int32)
+    fs.prim_geom = np.zeros((n, PRIM_STRIDE), np.float64)
+    fs.prim_mat = np.zeros(n, np.int32)
+    for i, o in enumerate(leaves):
+        g = fs.prim_geom[i]
+        if isinstance(o, hit.MovingSphere):
+            fs.prim_kind[i] = PRIM_MOVING
+            g[0:3], g[3], g[4:7], g[7], g[8] = o.center0, o.radius, o.center1, o.t0, o.t1
+        else:
+            fs.prim_kind[i] = PRIM_UVSPHERE if isinstance(o, hit.UVSphere) else PRIM_SPHERE
+            g[0:3], g[3], g[4:7], g[7], g[8] = o.center, o.radius, o.center, 0.0, 1.0
+        fs.prim_mat[i] = materials.get(o.material, build_mat)
+    fs.mat_kind = np.array([r[0] for r in materials.rows], np.int32)
+    fs.mat_tex = np.array([r[1] for r in materials.rows], np.int32)
+    fs.mat_param = np.array([r[2] for r in materials.rows], np.float64)
+    fs.tex_kind = np.array([r[0] for r in textures.rows], np.int32)
+    fs.tex_param = np.array([r[1] for r in textures.rows], np.float64).reshape(-1, TEX_STRIDE)
+    fs.tex_child = np.array([r[2] for r in textures.rows], np.int32).reshape(-1, 2)
+
+    if camera is not None:
+        fs.cam_kind, fs.cam = flatten_camera(camera)
+    return fs
+
+
+def flatten_camera(camera):
+    c = np.zeros(24, np.float64)
+    if isinstance(camera, cam.ThinLensCamera):
+        c[0:3], c[3:6], c[6:9], c[9:12] = camera.origin, camera.lleft, camera.horiz, camera.vert
+        c[12:15], c[15:18], c[18:21] = camera.u, camera.v, camera.w
+        c[21], c[22], c[23] = camera.aperture, camera.t0, camera.t1
+        return CAM_THINLENS, c
+    if isinstance(camera, cam.PinholeCamera):
+        c[0:3], c[3:6], c[6:9], c[9:12] = camera.origin, camera.lleft, camera.horiz, camera.vert
+        return CAM_PINHOLE, c
+    raise UnsupportedOnGpuPath("camera %s is not supported on the GPU path" % type(camera).__name__)

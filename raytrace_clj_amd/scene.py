@@ -1,0 +1,93 @@
+"""Host mirror of the in-scope part of raytrace-clj.scene (src/raytrace_clj/scene.clj): scene
+functions return {"camera": c, "world": w} exactly like the reference's {:camera c :world w}.
+
+make_random_scene = the Shirley cover scene (scene.clj:318-412); make_two_spheres = scene.clj:9-48.
+The reference draws scene randomness from the unseeded clojure.core/rand; here every (rand) is the
+next value of a seeded SplitMix64 stream, consumed in the reference's evaluation order (per grid cell:
+centre x, centre z, choose-mat, then the material's own draws; cells failing the :when filter still
+consume their three draws).  The other scene functions of scene.clj use records outside the GPU
+path's scope (rectangles, boxes, media, triangles, Perlin / image textures)."""
+import math
+
+import numpy as np
+
+from . import camera as cam
+from . import hitable as hit
+from . import shader as shad
+from . import texture as tex
+from .util import SplitMix64, vec3
+
+SCENE_SEED = 0x5EED0001
+
+
+def _aspect(nx, ny):
+    # (/ (float nx) (float ny)): both operands exact floats, the division is done in double
+    return float(np.float32(nx)) / float(np.float32(ny))
+
+
+def make_two_spheres(nx, ny, seed=SCENE_SEED):
+    """two touching spheres -- scene.clj:9-48"""
+    rng = SplitMix64(seed)
+    checker = tex.checkerboard(tex0=tex.constant(color=vec3(0.2, 0.3, 0.1)),
+                               tex1=tex.constant(color=vec3(0.9, 0.9, 0.9)), scale=10)
+    return {
+        "camera": cam.thin_lens_camera(lookfrom=vec3(13, 2, 3), lookat=vec3(0, 1, 0), vup=vec3(0, 1, 0), vfov=40,
+                                       aspect=_aspect(nx, ny), aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0),
+        "world": hit.make_bvh([
+            hit.uv_sphere(center=vec3(0, 0, 0), radius=1000,
+                          material=shad.diffuse_light(tex=tex.uv_gradient(co=vec3(1, 1, 1), cu=vec3(1, 1, 1),
+                                                                          cv=vec3(0.5, 0.7, 1.0), cuv=vec3(0.5, 0.7, 1.0)))),
+            hit.sphere(center=vec3(0, -10, 0), radius=10, material=shad.lambertian(albedo=checker)),
+            hit.uv_sphere(center=vec3(0, 2, 0), radius=2,
+                          material=shad.lambertian(albedo=tex.uv_gradient(co=vec3(0, 1, 0), cu=vec3(0, 1, 1),
+                                                                          cv=vec3(1, 0, 1), cuv=vec3(1, 0, 0)))),
+        ], 0.0, 1.0, rng),
+    }
+
+
+def make_random_scene(nx, ny, n, moving, seed=SCENE_SEED, mix=(0.8, 0.95), bvh=True):
+    """make a random scene -- scene.clj:318-412 (the cover scene is n=11).
+
+    mix = (diffuse threshold, metal threshold) of choose-mat, scene.clj:386,406: the reference's
+    (0.8, 0.95); BASELINE config 5 ("dielectric-heavy") uses (0.1, 0.2).
+    bvh=False returns a Hitlist instead of the make-bvh tree (same closest hits)."""
+    rng = SplitMix64(seed)
+    rand = rng.rand
+    camera = cam.thin_lens_camera(lookfrom=vec3(13, 2, 3), lookat=vec3(0, 0, 0), vup=vec3(0, 1, 0), vfov=20,
+                                  aspect=_aspect(nx, ny), aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0)
+    items = [
+        hit.uv_sphere(center=vec3(0, 0, 0), radius=1000,  # sky dome
+                      material=shad.diffuse_light(tex=tex.uv_gradient(co=vec3(1, 1, 1), cu=vec3(1, 1, 1),
+                                                                      cv=vec3(0.5, 0.7, 1.0), cuv=vec3(0.5, 0.7, 1.0)))),
+        hit.sphere(center=vec3(0, -1000, 0), radius=1000,  # ground
+                   material=shad.lambertian(albedo=tex.checkerboard(tex0=tex.constant(color=vec3(0.2, 0.3, 0.1)),
+                                                                    tex1=tex.constant(color=vec3(0.9, 0.9, 0.9)), scale=10))),
+        hit.sphere(center=vec3(0, 1, 0), radius=1, material=shad.dielectric(ri=1.5)),  # glass
+        hit.sphere(center=vec3(-4, 1, 0), radius=1,  # plastic
+                   material=shad.lambertian(albedo=tex.constant(color=vec3(0.4, 0.2, 0.1)))),
+        hit.sphere(center=vec3(4, 1, 0), radius=1,  # metal
+                   material=shad.metal(albedo=tex.constant(color=vec3(0.7, 0.6, 0.5)), fuzz=0.0)),
+    ]
+    for a in range(-n, n):
+        for b in range(-n, n):
+            center = vec3(a + 0.9 * rand(), 0.2, b + 0.9 * rand())
+            choose_mat = rand()
+            d = center - vec3(4, 0.2, 0)
+            if not math.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) > 0.9:
+                continue
+            if choose_mat < mix[0]:  # diffuse
+                if moving:
+                    center1 = center + vec3(0, 0.5 * rand(), 0)
+                    albedo = tex.constant(color=vec3(rand() * rand(), rand() * rand(), rand() * rand()))
+                    items.append(hit.moving_sphere(center0=center, t0=0.0, center1=center1, t1=1.0, radius=0.2,
+                                                   material=shad.lambertian(albedo=albedo)))
+                else:
+                    albedo = tex.constant(color=vec3(rand() * rand(), rand() * rand(), rand() * rand()))
+                    items.append(hit.sphere(center=center, radius=0.2, material=shad.lambertian(albedo=albedo)))
+            elif choose_mat < mix[1]:  # metal
+                albedo = tex.constant(color=vec3(0.5 * (rand() + 1), 0.5 * (rand() + 1), 0.5 * (rand() + 1)))
+                items.append(hit.sphere(center=center, radius=0.2, material=shad.metal(albedo=albedo, fuzz=0.5 * rand())))
+            else:  # glass
+                items.append(hit.sphere(center=center, radius=0.2, material=shad.dielectric(ri=1.5)))
+    world = hit.make_bvh(items, 0.0, 1.0, rng) if bvh else hit.hitlist(items=items)
+    return {"camera": camera, "world": world}

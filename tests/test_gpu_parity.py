@@ -1,0 +1,391 @@
+"""Parity tests proper: the HIP path (through the C-ABI, include/rtmi.h) against the CPU oracle on the same seeded
+inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes -- through size-independent
+properties.  Tolerances: ray geometry (t, p, normal, scattered direction, camera rays) is BIT-EXACT (all of it is
++ - * / sqrt, one IEEE rounding per reference operation on both sides); colours that pass through sin/asin/atan2/pow
+(ocml vs glibc, <= 1-2 ulp) are compared to 1e-12; images to pixel RMS <= 1e-4 (the north star's tolerance), and in
+practice to ~1e-15."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import raytrace_clj_amd as r
+from raytrace_clj_amd import core
+from raytrace_clj_amd import flatten as fl
+from raytrace_clj_amd.util import draw_bits, sample_key, vec3
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+FLT_MAX = 3.4028234663852886e38
+MATERIAL = r.shader.lambertian(albedo=r.texture.constant(color=vec3(0.8, 0.8, 0.8)))
+GRIDPOINTS = [25.0 * vec3(i, j, k) for i in (-1, 0, 1) for j in (-1, 0, 1) for k in (-1, 0, 1)]
+DIRECTIONS = [5.0 * vec3(i, j, k) for i in (-1, 0, 1) for j in (-1, 0, 1) for k in (-1, 0, 1) if (i, j, k) != (0, 0, 0)]
+RMS_TOL = 1e-4
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+class _Flat:
+    def __init__(self, z):
+        for k in ("prim_kind", "prim_geom", "prim_mat", "mat_kind", "mat_tex", "mat_param", "tex_kind", "tex_param", "tex_child", "cam"):
+            setattr(self, k, z[k])
+        self.cam_kind = int(z["cam_kind"])
+
+
+def dev(fs_or_scene):
+    if isinstance(fs_or_scene, _Flat):
+        f = fl.FlatScene()
+        for k in ("prim_kind", "prim_geom", "prim_mat", "mat_kind", "mat_tex", "mat_param", "tex_kind", "tex_param", "tex_child", "cam"):
+            setattr(f, k, getattr(fs_or_scene, k))
+        f.cam_kind = fs_or_scene.cam_kind
+        return core.DeviceScene(f)
+    return core.DeviceScene(fs_or_scene)
+
+
+def ray7(o, d, t=0.0):
+    return np.concatenate([o, d, [t]])
+
+
+def random_rays(n, seed, spread=3.0):
+    rng = np.random.default_rng(seed)
+    o = np.tile(vec3(13, 2, 3), (n, 1)) + rng.normal(0, 0.5, (n, 3))
+    d = -o + rng.normal(0, spread, (n, 3))
+    return np.concatenate([o, d, rng.random((n, 1))], axis=1)
+
+
+# ---- the arithmetic contract itself ---------------------------------------------------------------------------
+def test_device_arithmetic_is_ieee():
+    rng = np.random.default_rng(0)
+    abc = np.concatenate([rng.normal(0, 1, (20000, 3)) * 10.0 ** rng.integers(-8, 8, (20000, 1)),
+                          rng.random((20000, 3))])
+    out = core.probe_arith(abc)
+    a, b, c = abc[:, 0], abc[:, 1], abc[:, 2]
+    assert np.array_equal(out[:, 0], a / b), "f64 division must be correctly rounded"
+    assert np.array_equal(out[:, 1], np.sqrt(np.abs(a))), "f64 sqrt must be correctly rounded"
+    assert np.array_equal(out[:, 2], a * b + c), "a*b+c must not be contracted to an fma"
+
+
+def test_rng_stream(oracle):
+    cases = json.load(open(os.path.join(GOLD, "rng.json")))["cases"]
+    for c in cases:
+        k = int(c["key"])
+        assert core.sample_key(int(c["seed"]), int(c["pixel"]), int(c["sample"])) == k
+        bits, real = core.probe_rng(k, 0, 8, "f64")
+        assert [int(b) for b in bits] == [int(b) for b in c["bits"]] and list(real) == c["u53"]
+        bits, real = core.probe_rng(k, 0, 8, "f32")
+        assert list(real) == c["u24"]
+    bits, real = core.probe_rng(12345, 1000, 4096)
+    assert [int(b) for b in bits[:16]] == [draw_bits(12345, 1000 + d) for d in range(16)]
+    assert all(real[d] == oracle.draw(12345, 1000 + d) for d in range(0, 4096, 97))
+
+
+# ---- the reference's own tests, run on the device path (hitable_test.clj:23-103) -----------------------------------
+def test_reference_sphere_tests_on_device():
+    kat = json.load(open(os.path.join(GOLD, "reference_kat.json")))["sphere"]
+    for origin in GRIDPOINTS:
+        s = r.hitable.sphere(center=origin, radius=1.0, material=MATERIAL)
+        for d in DIRECTIONS[::5]:
+            assert r.core.hit(s, r.util.ray(origin + d, -d, 0.0), 0.0, FLT_MAX) is not None, "intersect ray"
+            assert r.core.hit(s, r.util.ray(origin + d, d, 0.1), 0.0, FLT_MAX) is None, "non-intersecting ray"
+    # whole lattice in one batch per sphere
+    for origin in GRIDPOINTS:
+        ds = core.DeviceScene(r.hitable.hitlist(items=[r.hitable.sphere(center=origin, radius=1.0, material=MATERIAL)]),
+                              r.camera.PinholeCamera(*(np.zeros(3),) * 4))
+        inward = np.array([ray7(origin + d, -d) for d in DIRECTIONS])
+        outward = np.array([ray7(origin + d, d, 0.1) for d in DIRECTIONS])
+        graze = np.array([ray7(origin + np.array(o, float), np.array(d, float)) for o, d in kat["grazing"]] + [ray7(origin, vec3(1, 1, 1))])
+        assert ds.probe_hit(inward, 0.0, FLT_MAX)[:, 0].all()
+        assert not ds.probe_hit(outward, 0.0, FLT_MAX)[:, 0].any()
+        assert ds.probe_hit(graze, 0.0, FLT_MAX)[:, 0].all(), "grazing rays (discriminant exactly 0) and ray from the centre"
+        ds.close()
+
+
+def test_reference_moving_sphere_tests_on_device():
+    t0, t1 = 0.1, 0.9
+    for origin in GRIDPOINTS[::2]:
+        s = r.hitable.moving_sphere(center0=origin, t0=t0, center1=origin + vec3(10, 20, 30), t1=t1, radius=1.0, material=MATERIAL)
+        ds = core.DeviceScene(r.hitable.hitlist(items=[s]), r.camera.PinholeCamera(*(np.zeros(3),) * 4))
+        assert ds.probe_hit(np.array([ray7(origin + d, -d, t0) for d in DIRECTIONS]), 0.0, FLT_MAX)[:, 0].all()
+        assert not ds.probe_hit(np.array([ray7(origin + d, d, t0) for d in DIRECTIONS]), 0.0, FLT_MAX)[:, 0].any()
+        assert ds.probe_hit(ray7(origin, vec3(1, 1, 1), t0), 0.0, FLT_MAX)[0, 0] == 1
+        # at t1 the sphere has moved away by (10,20,30)
+        assert not ds.probe_hit(np.array([ray7(origin + d, -d, t1) for d in DIRECTIONS]), 0.0, FLT_MAX)[:, 0].any()
+        ds.close()
+
+
+def test_analytic_hits_on_device():
+    s = r.hitable.sphere(center=vec3(0, 0, 0), radius=1.0, material=MATERIAL)
+    h = r.core.hit(s, r.util.ray(vec3(0, 0, -5), vec3(0, 0, 1), 0), 0.0, FLT_MAX)
+    assert h["t"] == 4.0 and list(h["p"]) == [0, 0, -1] and list(h["normal"]) == [0, 0, -1] and h["material"] is MATERIAL
+    h = r.core.hit(s, r.util.ray(vec3(1, 1, 0), vec3(-1, 0, 0), 0), 0.0, FLT_MAX)
+    assert h["t"] == 1.0 and list(h["normal"]) == [0, 1, 0]
+    assert r.core.hit(s, r.util.ray(vec3(0, 0, -5), vec3(0, 0, 1), 0), 4.0, FLT_MAX)["t"] == 6.0  # strict t > t-min
+    assert r.core.hit(s, r.util.ray(vec3(0, 0, -5), vec3(0, 0, 1), 0), 0.0, 4.0) is None      # strict t < t-max
+    # first-in-list wins exact ties (hitable.clj:20): two identical spheres
+    a = r.hitable.sphere(center=vec3(0, 0, 0), radius=1.0, material=MATERIAL)
+    b = r.hitable.sphere(center=vec3(0, 0, 0), radius=1.0, material=r.shader.dielectric(ri=1.5))
+    assert r.core.hit([a, b], r.util.ray(vec3(0, 0, -5), vec3(0, 0, 1), 0), 0.0, FLT_MAX)["material"] is MATERIAL
+    assert r.core.hit([b, a], r.util.ray(vec3(0, 0, -5), vec3(0, 0, 1), 0), 0.0, FLT_MAX)["material"] is b.material
+    # same tie between a static and a moving sphere (scanned in separate passes on the device)
+    m = r.hitable.moving_sphere(center0=vec3(0, 0, 0), t0=0.0, center1=vec3(0, 0, 0), t1=1.0, radius=1.0, material=r.shader.dielectric(ri=1.5))
+    assert r.core.hit([m, a], r.util.ray(vec3(0, 0, -5), vec3(0, 0, 1), 0.5), 0.0, FLT_MAX)["material"] is m.material
+    assert r.core.hit([a, m], r.util.ray(vec3(0, 0, -5), vec3(0, 0, 1), 0.5), 0.0, FLT_MAX)["material"] is MATERIAL
+
+
+# ---- protocol functions vs the oracle, bit for bit ------------------------------------------------------------------
+@pytest.mark.parametrize("moving", [False, True])
+def test_hit_matches_oracle(oracle, cover11, cover11_moving, moving):
+    f = fl.flatten(cover11_moving if moving else cover11)
+    rays = random_rays(20000, 3)
+    ds = core.DeviceScene(f)
+    got, exp = ds.probe_hit(rays), oracle.probe_hit(f, rays)
+    ds.close()
+    assert np.array_equal(got[:, :9], exp[:, :9]), "hit?, prim, t, p, normal must be bit-exact"
+    assert np.allclose(got[:, 9:], exp[:, 9:], atol=1e-15, rtol=0)  # uv: asin/atan2
+    assert 0.9 < exp[:, 0].mean() <= 1.0 and len(np.unique(exp[:, 1])) > 100
+
+
+def test_camera_matches_oracle(oracle, cover11):
+    f = fl.flatten(cover11)
+    rng = np.random.default_rng(1)
+    uv, keys = rng.random((5000, 2)), rng.integers(0, 2 ** 63, 5000, dtype=np.uint64)
+    ds = core.DeviceScene(f)
+    assert np.array_equal(ds.probe_camera(uv, keys), oracle.probe_camera(f, uv, keys))
+    ds.close()
+    # thin lens with a real aperture, and the pinhole camera
+    for camera in (r.camera.thin_lens_camera(lookfrom=vec3(3, 3, 2), lookat=vec3(0, 0, -1), vup=vec3(0, 1, 0), vfov=20, aspect=2.0,
+                                             aperture=2.0, focus_dist=5.2, t0=0.25, t1=0.75),
+                   r.camera.pinhole_camera(lookfrom=vec3(3, 3, 2), lookat=vec3(0, 0, -1), vup=vec3(0, 1, 0), vfov=90, aspect=1.5)):
+        f2 = fl.flatten(cover11["world"], camera)
+        ds = core.DeviceScene(f2)
+        got, exp = ds.probe_camera(uv, keys), oracle.probe_camera(f2, uv, keys)
+        ds.close()
+        assert np.array_equal(got, exp)
+    g = r.core.get_ray(cover11["camera"], 0.5, 0.5, key=12345)
+    assert np.allclose(g["direction"], (-9.636241116594, -1.482498633322, -2.223747949983), atol=1e-10)
+
+
+def test_textures_match_oracle(oracle, cover11):
+    f = fl.flatten(r.scene.make_two_spheres(40, 20))
+    rng = np.random.default_rng(2)
+    uvp = np.concatenate([rng.random((4000, 2)), rng.normal(0, 5, (4000, 3))], axis=1)
+    ds = core.DeviceScene(f)
+    for t in range(len(f.tex_kind)):
+        got, exp = ds.probe_texture(t, uvp), oracle.probe_texture(f, t, uvp)
+        if f.tex_kind[t] == fl.TEX_CHECKER:
+            assert (got == exp).all(axis=1).mean() > 0.9999  # sign of a product of sines: flips only within an ulp of a zero
+        else:
+            assert np.array_equal(got, exp)
+    ds.close()
+    assert np.allclose(r.core.sample(r.texture.uv_gradient(co=vec3(1, 1, 1), cu=vec3(1, 1, 1), cv=vec3(.5, .7, 1), cuv=vec3(.5, .7, 1)),
+                                     (0.5, 0.5), vec3(0, 0, 0)), (0.75, 0.85, 1.0))
+
+
+def test_scatter_matches_oracle(oracle):
+    mats = [r.shader.lambertian(albedo=r.texture.constant(color=vec3(0.4, 0.2, 0.1))),
+            r.shader.metal(albedo=r.texture.constant(color=vec3(0.7, 0.6, 0.5)), fuzz=0.0),
+            r.shader.metal(albedo=r.texture.constant(color=vec3(0.7, 0.6, 0.5)), fuzz=0.7),
+            r.shader.dielectric(ri=1.5), r.shader.dielectric(ri=2.4),
+            r.shader.diffuse_light(tex=r.texture.constant(color=vec3(4, 4, 4)))]
+    world = r.hitable.hitlist(items=[r.hitable.sphere(center=vec3(0, 0, 0), radius=1.0, material=m) for m in mats])
+    f = fl.flatten(world, r.camera.PinholeCamera(*(np.zeros(3),) * 4))
+    rng = np.random.default_rng(4)
+    n = 6000
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    rays = np.concatenate([rng.normal(size=(n, 3)), rng.normal(size=(n, 3)) * 3, rng.random((n, 1))], axis=1)
+    hits = np.concatenate([rng.normal(size=(n, 3)), nrm, rng.random((n, 2))], axis=1)
+    keys = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+    ds = core.DeviceScene(f)
+    for m in range(len(mats)):
+        got, exp = ds.probe_scatter(m, rays, hits, keys), oracle.probe_scatter(f, m, rays, hits, keys)
+        same = (got == exp).all(axis=1)
+        if f.mat_kind[m] == fl.MAT_DIELECTRIC:
+            assert same.mean() > 0.9995  # xi < schlick(pow): can flip only within an ulp of the threshold
+        else:
+            assert same.all(), "material %d" % m
+        if f.mat_kind[m] == fl.MAT_METAL:
+            assert 0 < exp[:, 0].mean() < 1  # some fuzzed/reflected directions end below the surface -> nil
+    ds.close()
+    # draw counts: dielectric draws once only when refraction is possible (shader.clj:91-93); light draws nothing
+    assert set(np.unique(exp[:, 8])) == {0.0}
+    sc = r.core.scatter(mats[1], r.util.ray(vec3(0, 2, 0), vec3(1, -1, 0), 0.3), {"p": vec3(1, 1, 0), "normal": vec3(0, 1, 0)}, key=5)
+    assert np.allclose(sc["scattered"]["direction"], vec3(1, 1, 0) / np.sqrt(2)) and sc["scattered"]["time"] == 0.3
+
+
+def test_paths_match_oracle_segment_by_segment(oracle, cover11_moving):
+    f = fl.flatten(cover11_moving)
+    n = 8192
+    keys = np.array([sample_key(99, i, 0) for i in range(n)], np.uint64)
+    rng = np.random.default_rng(6)
+    cam = oracle.probe_camera(f, rng.random((n, 2)), keys)
+    rays = cam[:, :7]
+    ds = core.DeviceScene(f)
+    rgb, nseg, log, nlog = ds.probe_paths(rays, keys, depth=50, ctr0=50, max_seg=12)
+    ds.close()
+    ergb, enseg, elog, enlog = oracle.probe_paths(f, rays, keys, depth=50, ctr0=50, max_seg=12)
+    assert np.array_equal(nseg, enseg) and np.array_equal(nlog, enlog)
+    assert np.array_equal(log, elog), "prim, t, p, normal, scattered direction of every logged segment must be bit-exact"
+    assert np.allclose(rgb, ergb, atol=1e-12, rtol=0)
+    assert enseg.max() >= 8 and enseg.mean() > 1.5
+
+
+def test_integrator_kats_on_device():
+    dome = r.hitable.uv_sphere(center=vec3(0, 0, 0), radius=1000, material=r.shader.diffuse_light(
+        tex=r.texture.uv_gradient(co=vec3(1, 1, 1), cu=vec3(1, 1, 1), cv=vec3(0.5, 0.7, 1.0), cuv=vec3(0.5, 0.7, 1.0))))
+    cam0 = r.camera.PinholeCamera(*(np.zeros(3),) * 4)
+    ds = core.DeviceScene(r.hitable.hitlist(items=[dome]), cam0)
+    rgb, nseg, _, _ = ds.probe_paths(np.array([ray7(vec3(0, 0, 0), vec3(0, 1, 0)), ray7(vec3(0, 0, 0), vec3(1, 0, 0))]), [1, 2])
+    ds.close()
+    assert list(nseg) == [1, 1] and np.allclose(rgb, [(1, 1, 1), (0.75, 0.85, 1)], atol=1e-12)
+    ds = core.DeviceScene(r.hitable.hitlist(items=[dome, r.hitable.sphere(center=vec3(0, 0, -5), radius=1.0, material=MATERIAL)]), cam0)
+    rgb, nseg, _, _ = ds.probe_paths(ray7(vec3(0, 0, 0), vec3(0, 0, -1)), [7], depth=0)
+    ds.close()
+    assert list(rgb[0]) == [0, 0, 0] and nseg[0] == 1
+    mirror = r.shader.metal(albedo=r.texture.constant(color=vec3(1, 1, 1)), fuzz=0.0)
+    ds = core.DeviceScene(r.hitable.hitlist(items=[r.hitable.sphere(center=vec3(0, 0, -1001), radius=1000.0, material=mirror),
+                                                   r.hitable.sphere(center=vec3(0, 0, 1001), radius=1000.0, material=mirror)]), cam0)
+    rgb, nseg, _, _ = ds.probe_paths(ray7(vec3(0, 0, 0), vec3(0, 0, 1)), [9])
+    ds.close()
+    assert nseg[0] == 51 and list(rgb[0]) == [0, 0, 0]
+
+
+# ---- whole renders ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["render_cover_n3.npz", "render_two_spheres.npz"])
+def test_render_matches_golden(name):
+    z = np.load(os.path.join(GOLD, name))
+    ds = dev(_Flat(z))
+    lin, q, cnt = ds.render(int(z["nx"]), int(z["ny"]), int(z["ns"]), int(z["depth"]), int(z["seed"]))
+    ds.close()
+    assert rms(lin, z["linear"]) <= RMS_TOL and rms(lin, z["linear"]) < 1e-13
+    assert np.array_equal(cnt, z["counters"])
+    assert (q != z["rgb8"]).mean() < 1e-3 and np.abs(q.astype(int) - z["rgb8"].astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("cfg", [(200, 100, 4, 11, False), (96, 56, 8, 11, True), (61, 37, 5, 3, False)])
+def test_render_matches_oracle(oracle, cfg):
+    nx, ny, ns, n, moving = cfg  # (200,100,4) is BASELINE config 0; 61x37 exercises partial 8x8 tiles
+    sc = r.scene.make_random_scene(nx, ny, n, moving)
+    f = fl.flatten(sc)
+    exp_lin, exp_q, exp_cnt = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, nthreads=16)
+    lin, q, cnt = r.render(sc, nx, ny, ns)
+    assert lin.shape == (ny, nx, 3)
+    assert rms(lin, exp_lin) <= RMS_TOL and rms(lin, exp_lin) < 1e-13
+    assert np.array_equal(cnt, exp_cnt), "total-rays / total-pixels"
+    assert np.abs(q.astype(int) - exp_q.astype(int)).max() <= 1 and (q != exp_q).mean() < 1e-3
+
+
+def test_render_region_and_errors(cover_small):
+    ds = core.DeviceScene(cover_small)
+    full, q, cnt = ds.render(48, 24, 2)
+    part, qp, cp = ds.render(48, 24, 2, region=(8, 4, 40, 20))
+    assert np.array_equal(part, full[4:20, 8:40]) and np.array_equal(qp, q[4:20, 8:40]) and cp[1] == 32 * 16
+    for bad in [dict(nx=0, ny=24, ns=2), dict(nx=48, ny=24, ns=0), dict(nx=48, ny=24, ns=2, depth=-1),
+                dict(nx=48, ny=24, ns=2, region=(0, 0, 49, 24)), dict(nx=48, ny=24, ns=2, region=(8, 8, 8, 9))]:
+        with pytest.raises(core.RtmiError) as e:
+            ds.render(**bad)
+        assert e.value.code == -1
+    ds.close()
+    f = fl.flatten(cover_small)
+    f.prim_kind = f.prim_kind.copy(); f.prim_kind[0] = 7  # e.g. a RectXY smuggled past the flattener
+    with pytest.raises(core.RtmiError) as e:
+        core.DeviceScene(f)
+    assert e.value.code == -3 and "unsupported on GPU path" in str(e.value)
+    f = fl.flatten(cover_small)
+    f.prim_mat = f.prim_mat.copy(); f.prim_mat[0] = 10 ** 6
+    with pytest.raises(core.RtmiError) as e:
+        core.DeviceScene(f)
+    assert e.value.code == -1
+    empty = core.DeviceScene(r.hitable.hitlist(items=[]), cover_small["camera"])
+    lin, q, cnt = empty.render(16, 8, 2)  # empty world: every sample misses -> black, one segment each
+    empty.close()
+    assert not lin.any() and not q.any() and cnt[0] == 16 * 8 * 2
+
+
+# ---- full BASELINE sizes: size-independent properties ----------------------------------------------------------------
+def test_full_size_properties():
+    """BASELINE config 1 (800x400x64, cover scene n=11): the oracle cannot finish this in seconds, so the image is
+    checked through invariances: run-to-run determinism, invariance to the sample-buffer pass split, to the LDS sphere
+    tiling, to the launch geometry and to the tile partition (the 8-GPU path), and oracle spot checks on sub-regions."""
+    import torch
+    nx, ny, ns = 800, 400, 64
+    sc = r.scene.make_random_scene(nx, ny, 11, False)
+    ctx = core.Context(0)
+    ds = core.DeviceScene(sc, ctx=ctx)
+    base, q, cnt = ds.render(nx, ny, ns)
+    again, q2, cnt2 = ds.render(nx, ny, ns)
+    assert np.array_equal(base, again) and np.array_equal(q, q2) and np.array_equal(cnt, cnt2), "deterministic"
+    assert cnt[1] == nx * ny and nx * ny * ns <= cnt[0] <= nx * ny * ns * 51
+    ctx.set_option("workspace_bytes", 32 << 20)  # -> many sample passes
+    multi_pass, _, cnt3 = ds.render(nx, ny, ns)
+    ctx.set_option("workspace_bytes", 8 << 30)
+    assert np.array_equal(base, multi_pass) and np.array_equal(cnt, cnt3), "sample-pass split must not change the image"
+    ctx.set_option("lds_tile_bytes", 4096)  # 128 spheres per LDS tile -> multi-tile scan with barriers
+    tiled, _, cnt4 = ds.render(nx, ny, ns)
+    ctx.set_option("lds_tile_bytes", 64 * 1024 - 64)
+    assert np.array_equal(base, tiled) and np.array_equal(cnt, cnt4), "LDS sphere tiling must not change the image"
+    ctx.set_option("blocks_per_cu", 1)
+    geo, _, _ = ds.render(nx, ny, ns)
+    ctx.set_option("blocks_per_cu", 2)
+    assert np.array_equal(base, geo), "launch geometry must not change the image"
+    # tile partition over 8 "ranks", rendered one after the other, then assembled
+    L = r._ffi.lib()
+    world = 8
+    per = int(L.rtmi_local_tiles(nx, ny, 0, world))
+    gathered = torch.zeros((world, per, 64, 3), dtype=torch.float64, device="cuda")
+    counters = torch.zeros((world, 2), dtype=torch.int64, device="cuda")
+    for rank in range(world):
+        ds.render_tiles_device(nx, ny, ns, rank, world, gathered[rank], counters[rank])
+    out = torch.zeros((ny, nx, 3), dtype=torch.float64, device="cuda")
+    out8 = torch.zeros((ny, nx, 3), dtype=torch.uint8, device="cuda")
+    core.check(L.rtmi_assemble_device(ctx.handle, nx, ny, world, per, r._ffi.ptr(gathered), r._ffi.ptr(out), r._ffi.ptr(out8), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), base) and np.array_equal(out8.cpu().numpy(), q), "tile partition invariance"
+    assert int(counters[:, 0].sum()) == int(cnt[0]) and int(counters[:, 1].sum()) == nx * ny
+    ds.close()
+    ctx.close()
+    # physical sanity of the picture: sky on top, ground below, nothing NaN
+    assert np.isfinite(base).all() and base[:20].mean() > 0.5 and base.min() >= 0
+
+
+def test_full_size_spot_checks_against_oracle(oracle):
+    nx, ny, ns = 800, 400, 64
+    sc = r.scene.make_random_scene(nx, ny, 11, False)
+    f = fl.flatten(sc)
+    ds = core.DeviceScene(f)
+    for region in [(392, 196, 408, 204), (0, 0, 16, 8), (600, 300, 616, 308)]:
+        lin, q, _ = ds.render(nx, ny, ns, region=region)
+        exp, eq, _ = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, region=region, nthreads=16)
+        assert rms(lin, exp) <= RMS_TOL and rms(lin, exp) < 1e-13
+        assert np.abs(q.astype(int) - eq.astype(int)).max() <= 1
+    ds.close()
+
+
+def test_config3_scene_10k_spheres_spot_check(oracle):
+    """BASELINE config 2 scene (n=50, ~10k spheres): more spheres than one LDS tile holds -> the multi-tile scan."""
+    nx, ny, ns = 1920, 1080, 4
+    sc = r.scene.make_random_scene(nx, ny, 50, False)
+    f = fl.flatten(sc)
+    assert f.n_prims > 9900
+    ds = core.DeviceScene(f)
+    region = (952, 620, 968, 628)
+    lin, q, _ = ds.render(nx, ny, ns, region=region)  # the host entry renders the whole frame, then crops
+    ds.close()
+    exp, eq, _ = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, region=region, nthreads=16)
+    assert rms(lin, exp) <= RMS_TOL and rms(lin, exp) < 1e-13
+
+
+def test_dielectric_heavy_scene(oracle):
+    """BASELINE config 4's scene definition (80 % glass): long specular chains, the chaotic case for parity."""
+    nx, ny, ns = 160, 80, 16
+    sc = r.scene.make_random_scene(nx, ny, 11, False, mix=(0.1, 0.2))
+    f = fl.flatten(sc)
+    lin, q, cnt = r.render(sc, nx, ny, ns)
+    exp, eq, ecnt = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, nthreads=16)
+    assert np.array_equal(cnt, ecnt)
+    assert rms(lin, exp) <= RMS_TOL and rms(lin, exp) < 1e-13
+    assert cnt[0] / (nx * ny * ns) > 2.5  # paths really are long here

@@ -1,0 +1,195 @@
+"""CPU tests of the host logic: the reference-protocol mirror, the flattener, the scene generator, the
+golden fixtures against the oracle, and that librtmi.so loads and exports every symbol include/rtmi.h declares
+(no compute call is made here: there is no GPU)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import raytrace_clj_amd as r
+from raytrace_clj_amd import _ffi
+from raytrace_clj_amd import flatten as fl
+from raytrace_clj_amd.util import vec3
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+class _Flat:
+    def __init__(self, z):
+        for k in ("prim_kind", "prim_geom", "prim_mat", "mat_kind", "mat_tex", "mat_param", "tex_kind", "tex_param", "tex_child", "cam"):
+            setattr(self, k, z[k])
+        self.cam_kind = int(z["cam_kind"])
+
+
+# ---- util_test.clj:7-41 (vec3, ray) on the host mirror ---------------------------------------------------------
+def test_vec3_and_ray():
+    for v in (vec3(1, 2, 3), vec3(1.0, 2.0, 3.0)):
+        assert v.dtype == np.float64 and list(v) == [1.0, 2.0, 3.0]
+    from fractions import Fraction
+    assert list(vec3(Fraction(1, 2), Fraction(1, 4), Fraction(1, 8))) == [0.5, 0.25, 0.125]
+    with pytest.raises(IndexError):
+        vec3(1, 2, 3)[3]
+    rr = r.util.ray(vec3(1, 2, 3), vec3(4, 5, 6), 0.1)
+    assert set(rr) == {"origin", "direction", "time"} and rr["time"] == 0.1
+    assert list(r.util.point_at_parameter(rr, 1)) == [5, 7, 9] and list(r.util.point_at_parameter(rr, -1)) == [-3, -3, -3]
+
+
+def test_record_field_names_match_reference():
+    import dataclasses as dc
+    names = lambda c: [f.name for f in dc.fields(c)]
+    assert names(r.hitable.Hitlist) == ["items"] and names(r.hitable.bvh_node) == ["left", "right", "box"]
+    assert names(r.hitable.Sphere) == names(r.hitable.UVSphere) == ["center", "radius", "material"]
+    assert names(r.hitable.MovingSphere) == ["center0", "t0", "center1", "t1", "radius", "material"]
+    assert names(r.hitable.AABB) == ["vmin", "vmax"]
+    assert names(r.shader.Lambertian) == ["albedo"] and names(r.shader.Metal) == ["albedo", "fuzz"]
+    assert names(r.shader.Dielectric) == ["ri"] and names(r.shader.DiffuseLight) == ["tex"]
+    assert names(r.texture.Constant) == ["color"] and names(r.texture.Checkerboard) == ["tex0", "tex1", "scale"]
+    assert names(r.texture.UVGradient) == ["co", "cu", "cv", "cuv"]
+    assert names(r.camera.PinholeCamera) == ["origin", "lleft", "horiz", "vert"]
+    assert names(r.camera.ThinLensCamera) == ["origin", "lleft", "horiz", "vert", "u", "v", "w", "aperture", "t0", "t1"]
+
+
+def test_make_bvh_shapes():
+    m = r.shader.dielectric(ri=1.5)
+    pts = [vec3(0, 0, 0), vec3(1, 2, 3), vec3(-2, -1, -3), vec3(3, -1, 2), vec3(-3, 2, 1)]  # hitable_test.clj:150-156
+    spheres = [r.hitable.sphere(center=p, radius=0.1, material=m) for p in pts]
+    one = r.hitable.make_bvh(spheres[:1], 0, 1)
+    assert one.left is one.right is spheres[0]  # hitable.clj:113-114
+    tree = r.hitable.make_bvh(spheres, 0, 1)
+    assert isinstance(tree, r.hitable.bvh_node)
+    assert np.array_equal(tree.box.vmin, [-3.1, -1.1, -3.1]) and np.array_equal(tree.box.vmax, [3.1, 2.1, 3.1])
+    f = fl.flatten(tree, r.camera.pinhole_camera(lookfrom=vec3(0, 0, 5), lookat=vec3(0, 0, 0), vup=vec3(0, 1, 0), vfov=40, aspect=2))
+    assert f.n_prims == 5 and len(f.mat_kind) == 1  # leaves de-duplicated, material interned
+    assert fl.flatten(one, None).n_prims == 1
+
+
+def test_flatten_cover_scene(cover11, cover11_moving):
+    f = fl.flatten(cover11)
+    assert 485 <= f.n_prims <= 489  # 484 candidates minus those near (4,.2,0) plus 5 hero
+    assert (f.prim_kind == fl.PRIM_UVSPHERE).sum() == 1 and (f.prim_kind == fl.PRIM_MOVING).sum() == 0
+    kinds = f.mat_kind[f.prim_mat]
+    small = f.prim_geom[:, 3] == 0.2
+    frac = [(kinds[small] == k).mean() for k in (fl.MAT_LAMBERTIAN, fl.MAT_METAL, fl.MAT_DIELECTRIC)]
+    assert 0.7 < frac[0] < 0.9 and 0.08 < frac[1] < 0.22 and 0.01 < frac[2] < 0.1
+    assert (f.tex_kind == fl.TEX_CHECKER).sum() == 1 and (f.tex_kind == fl.TEX_UVGRADIENT).sum() == 1
+    ck = int(np.flatnonzero(f.tex_kind == fl.TEX_CHECKER)[0])
+    assert f.tex_param[ck, 0] == 10 and (f.tex_child[ck] < ck).all()
+    d = np.linalg.norm(f.prim_geom[small, 0:3] - vec3(4, 0.2, 0), axis=1)
+    assert (d > 0.9).all()  # scene.clj:375
+    fm = fl.flatten(cover11_moving)
+    mv = fm.prim_kind == fl.PRIM_MOVING
+    assert mv.sum() > 300 and (fm.prim_geom[mv, 7] == 0).all() and (fm.prim_geom[mv, 8] == 1).all()
+    dy = fm.prim_geom[mv, 5] - fm.prim_geom[mv, 1]
+    assert (dy >= 0).all() and (dy < 0.5).all() and (fm.prim_geom[mv, 4] == fm.prim_geom[mv, 0]).all()
+    # seeded: same seed -> same scene, another seed -> another scene; a bvh world and a hitlist world hold the same leaves
+    again = fl.flatten(r.scene.make_random_scene(200, 100, 11, False))
+    assert np.array_equal(np.sort(again.prim_geom, axis=0), np.sort(f.prim_geom, axis=0))
+    other = fl.flatten(r.scene.make_random_scene(200, 100, 11, False, seed=99))
+    assert not np.array_equal(np.sort(other.prim_geom, axis=0), np.sort(f.prim_geom, axis=0))
+    hl = fl.flatten(r.scene.make_random_scene(200, 100, 11, False, bvh=False))
+    assert hl.n_prims == f.n_prims and hl.prim_kind[0] == fl.PRIM_UVSPHERE and hl.prim_geom[1, 1] == -1000
+    n50 = fl.flatten(r.scene.make_random_scene(1920, 1080, 50, False))
+    assert 9990 <= n50.n_prims <= 10005
+    heavy = fl.flatten(r.scene.make_random_scene(200, 100, 11, False, mix=(0.1, 0.2)))
+    hk = heavy.mat_kind[heavy.prim_mat][heavy.prim_geom[:, 3] == 0.2]
+    assert (hk == fl.MAT_DIELECTRIC).mean() > 0.7
+
+
+def test_flatten_rejects_unknown_records():
+    class RectXY:
+        pass
+    with pytest.raises(r.UnsupportedOnGpuPath):
+        fl.flatten(r.hitable.hitlist(items=[RectXY()]), None)
+    class Isotropic(r.shader.Shader):
+        pass
+    with pytest.raises(r.UnsupportedOnGpuPath):
+        fl.flatten(r.hitable.hitlist(items=[r.hitable.sphere(center=vec3(0, 0, 0), radius=1, material=Isotropic())]), None)
+    class Marble(r.texture.Texture):
+        pass
+    with pytest.raises(r.UnsupportedOnGpuPath):
+        fl.flatten(r.hitable.hitlist(items=[r.hitable.sphere(center=vec3(0, 0, 0), radius=1, material=r.shader.lambertian(albedo=Marble()))]), None)
+
+
+# ---- golden fixtures: the oracle reproduces them (so a changed oracle cannot silently move the goalposts) ------------
+def test_golden_rng():
+    cases = json.load(open(os.path.join(GOLD, "rng.json")))["cases"]
+    from oracle.oracle import Oracle
+    o64, o32 = Oracle("f64"), Oracle("f32")
+    for c in cases:
+        k = int(c["key"])
+        assert o64.sample_key(int(c["seed"]), int(c["pixel"]), int(c["sample"])) == k
+        for d, (b, u53, u24) in enumerate(zip(c["bits"], c["u53"], c["u24"])):
+            assert o64.draw_bits(k, d) == int(b) and o64.draw(k, d) == u53 and o32.draw(k, d) == u24
+
+
+@pytest.mark.parametrize("name", ["render_cover_n3.npz", "render_two_spheres.npz"])
+def test_golden_renders(oracle, name):
+    z = np.load(os.path.join(GOLD, name))
+    lin, q, cnt = oracle.render(_Flat(z), int(z["nx"]), int(z["ny"]), int(z["ns"]), int(z["depth"]), int(z["seed"]), nthreads=4)
+    assert np.array_equal(lin, z["linear"]) and np.array_equal(q, z["rgb8"]) and np.array_equal(cnt, z["counters"])
+
+
+def test_golden_scene_generator_is_stable():
+    z = np.load(os.path.join(GOLD, "render_cover_n3.npz"))
+    f = fl.flatten(r.scene.make_random_scene(48, 24, 3, False))
+    assert np.array_equal(f.prim_geom, z["prim_geom"]) and np.array_equal(f.cam, z["cam"]) and np.array_equal(f.tex_param, z["tex_param"])
+
+
+def test_golden_paths(oracle):
+    z = np.load(os.path.join(GOLD, "paths_cover11_moving.npz"))
+    rgb, nseg, log, nlog = oracle.probe_paths(_Flat(z), z["rays"], z["keys"], int(z["depth"]), int(z["ctr0"]), max_seg=8)
+    assert np.array_equal(rgb, z["rgb"]) and np.array_equal(nseg, z["nseg"]) and np.array_equal(log, z["log"])
+    assert nseg.max() > 3 and (z["log"][:, :, 0].max() > 5)
+
+
+def test_f32_oracle_close_to_f64(oracle, oracle_f32, cover_small):
+    f = fl.flatten(cover_small)
+    a, _, _ = oracle.render(f, 24, 12, 16, seed=5)
+    b, _, _ = oracle_f32.render(f, 24, 12, 16, seed=5)
+    assert np.sqrt(np.mean((a - b) ** 2)) < 0.08  # different uniforms (24 vs 53 bits) and chaotic paths: statistical only
+
+
+# ---- the C-ABI library: loads, and exports exactly what include/rtmi.h declares ---------------------------------
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rtmi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtmi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_ffi.LIB_PATH), "build with `make -C raytrace_clj_amd/csrc` or __graft_entry__.build()"
+    L = ctypes.CDLL(_ffi.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(_ffi.SYMBOLS) == declared  # the python binding covers the whole header
+    L.rtmi_backend_name.restype = ctypes.c_char_p
+    assert L.rtmi_backend_name() == b"hip-gfx950"
+    L.rtmi_sample_key.restype = ctypes.c_uint64
+    L.rtmi_sample_key.argtypes = [ctypes.c_uint64] * 3
+    assert L.rtmi_sample_key(0x5EED0002, 319999, 63) == r.util.sample_key(0x5EED0002, 319999, 63)  # pure host function
+    assert L.rtmi_local_tiles(800, 400, 0, 1) == 5000 and L.rtmi_local_tiles(800, 400, 3, 8) == 625
+    assert L.rtmi_local_tiles(200, 100, 0, 1) == 25 * 13
+
+
+def test_no_device_is_a_loud_error():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_ffi.RtmiError) as e:
+        r.Context(0)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "raytrace_clj_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in src.replace("no oracle", ""), fn

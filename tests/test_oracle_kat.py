@@ -1,0 +1,274 @@
+"""Pins the CPU oracle (oracle/rt_oracle.c) with the known-answer data the reference's own tests hold
+(test/raytrace_clj/util_test.clj, test/raytrace_clj/hitable_test.clj) and with analytic values derived
+from the cited formulas."""
+import itertools
+import math
+
+import numpy as np
+import pytest
+
+import raytrace_clj_amd as r
+from raytrace_clj_amd import flatten as fl
+from raytrace_clj_amd.util import vec3
+
+FLT_MAX = 3.4028234663852886e38
+MATERIAL = r.shader.lambertian(albedo=r.texture.constant(color=vec3(0.8, 0.8, 0.8)))  # hitable_test.clj:21
+
+# hitable_test.clj:8-19
+GRIDPOINTS = [25.0 * vec3(i, j, k) for i in (-1, 0, 1) for j in (-1, 0, 1) for k in (-1, 0, 1)]
+DIRECTIONS = [5.0 * vec3(i, j, k) for i in (-1, 0, 1) for j in (-1, 0, 1) for k in (-1, 0, 1) if (i, j, k) != (0, 0, 0)]
+
+
+def world_of(*items):
+    return fl.flatten(r.hitable.hitlist(items=list(items)), r.camera.PinholeCamera(*(np.zeros(3),) * 4))
+
+
+def ray7(o, d, t=0.0):
+    return np.concatenate([o, d, [t]])
+
+
+# ---- K1: util_test.clj:44-49 ---------------------------------------------------------------------------
+def test_k1_point_at_parameter(oracle):
+    o, d = vec3(1, 2, 3), vec3(4, 5, 6)
+    assert np.array_equal(oracle.point_at_parameter(o, d, 0), vec3(1, 2, 3))
+    assert np.array_equal(oracle.point_at_parameter(o, d, 1), vec3(5, 7, 9))
+    assert np.array_equal(oracle.point_at_parameter(o, d, -1), vec3(-3, -3, -3))
+
+
+# ---- K2/K3: hitable_test.clj:23-59 ---------------------------------------------------------------------
+def test_k2_sphere_lattice(oracle):
+    for origin in GRIDPOINTS:
+        s = r.hitable.sphere(center=origin, radius=1.0, material=MATERIAL)
+        w = world_of(s)
+        inward = np.array([ray7(origin + d, -d, 0.0) for d in DIRECTIONS])
+        outward = np.array([ray7(origin + d, d, 0.1) for d in DIRECTIONS])
+        assert oracle.probe_hit(w, inward, 0.0, FLT_MAX)[:, 0].all(), "intersect ray"
+        assert not oracle.probe_hit(w, outward, 0.0, FLT_MAX)[:, 0].any(), "non-intersecting ray"
+        graze = np.array([ray7(origin + vec3(1, 1, 0), vec3(-1, 0, 0)), ray7(origin + vec3(1, 1, 0), vec3(0, -1, 0)),
+                          ray7(origin + vec3(1, 0, 1), vec3(0, 0, -1)), ray7(origin, vec3(1, 1, 1))])
+        assert oracle.probe_hit(w, graze, 0.0, FLT_MAX)[:, 0].all(), "grazing rays x/y/z and ray from inside"
+
+
+def test_k3_sphere_bbox(oracle):
+    for origin in GRIDPOINTS:
+        w = world_of(r.hitable.sphere(center=origin, radius=1.0, material=MATERIAL))
+        vmin, vmax = oracle.prim_bbox(w, 0, 0, 0)
+        assert np.array_equal(vmin, origin - 1.0) and np.array_equal(vmax, origin + 1.0)
+        b = r.hitable.sphere(center=origin, radius=1.0, material=MATERIAL).bbox(0, 0)  # host mirror, same data
+        assert np.array_equal(b.vmin, origin - 1.0) and np.array_equal(b.vmax, origin + 1.0)
+
+
+# ---- K4/K5: hitable_test.clj:61-103 ---------------------------------------------------------------------
+def test_k4_moving_sphere(oracle):
+    t0, t1 = 0.1, 0.9
+    for origin in GRIDPOINTS:
+        s = r.hitable.moving_sphere(center0=origin, t0=t0, center1=origin + vec3(10, 20, 30), t1=t1, radius=1.0, material=MATERIAL)
+        w = world_of(s)
+        inward = np.array([ray7(origin + d, -d, t0) for d in DIRECTIONS])
+        outward = np.array([ray7(origin + d, d, t0) for d in DIRECTIONS])
+        assert oracle.probe_hit(w, inward, 0.0, FLT_MAX)[:, 0].all()
+        assert not oracle.probe_hit(w, outward, 0.0, FLT_MAX)[:, 0].any()
+        assert oracle.probe_hit(w, ray7(origin, vec3(1, 1, 1), t0), 0.0, FLT_MAX)[0, 0] == 1, "ray from inside"
+        vmin, vmax = oracle.prim_bbox(w, 0, t0, t0)
+        assert np.array_equal(vmin, origin - 1.0) and np.array_equal(vmax, origin + 1.0)
+        b = s.bbox(t0, t0)
+        assert np.array_equal(b.vmin, origin - 1.0) and np.array_equal(b.vmax, origin + 1.0)
+
+
+def test_k5_center_at_time(oracle):
+    pa, pb = vec3(0, 0, 0), vec3(1, 2, 3)
+    assert np.array_equal(oracle.center_at_time(pa, 0, pb, 1, 0), pa)
+    assert np.array_equal(oracle.center_at_time(pa, 0, pb, 1, 1), pb)
+    assert np.array_equal(oracle.center_at_time(pa, 0, pb, 1, 0.5), vec3(0.5, 1.0, 1.5))
+    assert np.array_equal(r.hitable.center_at_time(pa, 0, pb, 1, 0.5), vec3(0.5, 1.0, 1.5))
+
+
+# ---- K6/K7: hitable_test.clj:106-141 -------------------------------------------------------------------
+def test_k6_aabb(oracle):
+    a, b = vec3(-1, -1, -1), vec3(1, 1, 1)
+    cases = [(vec3(0, 0, 0), vec3(1, 1, 1)), (vec3(-2, 0, 0), vec3(1, 0, 0)), (vec3(0, -2, 0), vec3(0, 1, 0)),
+             (vec3(0, 0, -2), vec3(0, 0, 1)), (vec3(-2, 1, 0), vec3(1, 0, 0)), (vec3(1, -2, 0), vec3(0, 1, 0)),
+             (vec3(1, 0, -2), vec3(0, 0, 1))]
+    for o, d in cases:
+        assert oracle.aabb_hit(a, b, o, d, 0.0, FLT_MAX), (o, d)
+
+
+def test_k7_surrounding_bbox(oracle):
+    w = world_of(r.hitable.sphere(center=vec3(-1, 2, -3), radius=0.1, material=MATERIAL),
+                 r.hitable.sphere(center=vec3(1, -2, 3), radius=0.1, material=MATERIAL))
+    vmin, vmax = oracle.surrounding_bbox(oracle.prim_bbox(w, 0), oracle.prim_bbox(w, 1))
+    assert list(vmin) == [-1.1, -2.1, -3.1] and list(vmax) == [1.1, 2.1, 3.1]
+    hb = r.hitable.make_surrounding_bbox(r.hitable.sphere(center=vec3(-1, 2, -3), radius=0.1, material=None).bbox(0, 0),
+                                         r.hitable.sphere(center=vec3(1, -2, 3), radius=0.1, material=None).bbox(0, 0))
+    assert list(hb.vmin) == [-1.1, -2.1, -3.1] and list(hb.vmax) == [1.1, 2.1, 3.1]
+
+
+# ---- K8: analytic sphere hits (hitable.clj:180-207) -----------------------------------------------------
+def test_k8_sphere_analytic(oracle):
+    w = world_of(r.hitable.sphere(center=vec3(0, 0, 0), radius=1.0, material=MATERIAL))
+    h = oracle.probe_hit(w, ray7(vec3(0, 0, -5), vec3(0, 0, 1)), 0.0, FLT_MAX)[0]
+    assert h[0] == 1 and h[2] == 4.0 and list(h[3:6]) == [0, 0, -1] and list(h[6:9]) == [0, 0, -1]
+    h = oracle.probe_hit(w, ray7(vec3(0, 0, 0), vec3(1, 1, 1)), 0.0, FLT_MAX)[0]
+    assert h[2] == pytest.approx(0.5773502691896257, abs=1e-15)
+    assert np.allclose(h[6:9], 0.5773502691896257, atol=1e-15)
+    h = oracle.probe_hit(w, ray7(vec3(1, 1, 0), vec3(-1, 0, 0)), 0.0, FLT_MAX)[0]  # discriminant exactly 0
+    assert h[0] == 1 and h[2] == 1.0 and list(h[6:9]) == [0, 1, 0]
+    # strict interval: t == t-min is rejected (hitable.clj:195)
+    assert oracle.probe_hit(w, ray7(vec3(0, 0, -5), vec3(0, 0, 1)), 4.0, FLT_MAX)[0, 2] == 6.0
+    assert oracle.probe_hit(w, ray7(vec3(0, 0, -5), vec3(0, 0, 1)), 0.0, 4.0)[0, 0] == 0
+
+
+# ---- K9/K10: shader.clj:6-20, 69-74 -------------------------------------------------------------------
+def test_k9_schlick(oracle):
+    assert oracle.schlick(1.0, 1.5) == 0.04000000000000001
+    assert oracle.schlick(0.0, 1.5) == 1.0
+    assert oracle.schlick(0.5, 1.5) == pytest.approx(0.07, abs=1e-16)
+
+
+def test_k10_reflect_refract(oracle):
+    assert list(oracle.reflect(vec3(1, -1, 0), vec3(0, 1, 0))) == [1, 1, 0]
+    assert np.allclose(oracle.refract(vec3(0, -1, 0), vec3(0, 1, 0), 1 / 1.5), [0, -1, 0], atol=1e-16)
+    assert oracle.refract(vec3(1, -0.01, 0), vec3(0, 1, 0), 1.5) is None  # total internal reflection
+
+
+# ---- K11: sky dome uv / emission (hitable.clj:128-139, texture.clj:26-34, scene.clj:336-344) --------------
+def test_k11_dome(oracle, cover11):
+    w = fl.flatten(cover11)
+    dome = int(np.flatnonzero(w.prim_kind == fl.PRIM_UVSPHERE)[0])  # leaf order is the bvh's, not the list's
+    assert w.prim_geom[dome, 3] == 1000
+    dome_tex = int(w.mat_tex[w.prim_mat[dome]])
+    cases = [((0, 1, 0), (0.5, 1.0), (1, 1, 1), (255, 255, 255)),
+             ((1, 0, 0), (0.5, 0.5), (0.75, 0.85, 1), (221, 236, 255)),
+             ((0, -1, 0), (0.5, 0.0), (0.5, 0.7, 1), (181, 214, 255)),
+             ((0, 0, 1), (0.25, 0.5), (0.75, 0.85, 1), None),
+             ((0.6, 0.8, 0), (0.5, 0.795167), (0.897584, 0.93855, 1), (242, 248, 255))]
+    for n, uv, rgb, q in cases:
+        got_uv = oracle.sphere_uv(vec3(*n))
+        assert np.allclose(got_uv, uv, atol=1e-6)
+        col = oracle.probe_texture(w, dome_tex, np.concatenate([got_uv, [0, 0, 0]]))[0]
+        assert np.allclose(col, rgb, atol=1e-6)
+        if q:
+            assert tuple(oracle.quantise(col)) == q
+
+
+# ---- K12: cover camera at aspect 2 (camera.clj:50-66, scene.clj:321-330) ------------------------------------
+def test_k12_camera(oracle, cover11):
+    c = fl.flatten(cover11).cam
+    exp = dict(w=(0.963624111659, 0.148249863332, 0.222374794998), u=(0.224859506699, 0, -0.974391195695),
+               v=(-0.144453361594, 0.988949937066, -0.033335391137), lleft=(2.82549317644, -1.226284198068, 4.271260490031),
+               horiz=(1.585951915991, 0, -6.87245830263), vert=(-0.509420502061, 3.487571129492, -0.117558577399))
+    assert np.allclose(c[18:21], exp["w"], atol=1e-11) and np.allclose(c[12:15], exp["u"], atol=1e-11)
+    assert np.allclose(c[15:18], exp["v"], atol=1e-11) and np.allclose(c[3:6], exp["lleft"], atol=1e-11)
+    assert np.allclose(c[6:9], exp["horiz"], atol=1e-11) and np.allclose(c[9:12], exp["vert"], atol=1e-11)
+    # the oracle's own ctor (same formulas in C) agrees bit for bit with the host mirror
+    oc = oracle.make_camera(1, vec3(13, 2, 3), vec3(0, 0, 0), vec3(0, 1, 0), 20, 2.0, 0.0, 10.0, 0.0, 1.0)
+    assert np.array_equal(oc, c)
+    # centre ray = -10 w; thin lens consumes disk draws (>= 2) and one time draw even at aperture 0
+    ray = oracle.probe_camera(fl.flatten(cover11), [0.5, 0.5], [12345])[0]
+    assert np.allclose(ray[3:6], (-9.636241116594, -1.482498633322, -2.223747949983), atol=1e-10)
+    assert np.array_equal(ray[0:3], [13, 2, 3]) and ray[7] >= 3 and (ray[7] - 1) % 2 == 0 and 0 <= ray[6] < 1
+
+
+# ---- K13: integrator (core.clj:17-41) -------------------------------------------------------------------
+def _dome():
+    return r.hitable.uv_sphere(center=vec3(0, 0, 0), radius=1000, material=r.shader.diffuse_light(
+        tex=r.texture.uv_gradient(co=vec3(1, 1, 1), cu=vec3(1, 1, 1), cv=vec3(0.5, 0.7, 1.0), cuv=vec3(0.5, 0.7, 1.0))))
+
+
+def test_k13_integrator(oracle):
+    # dome-only world: every sample = emitted(dome), exactly one segment
+    w = world_of(_dome())
+    rays = np.array([ray7(vec3(0, 0, 0), vec3(0, 1, 0)), ray7(vec3(0, 0, 0), vec3(1, 0, 0)), ray7(vec3(1, 2, 3), vec3(0, -1, 0))])
+    rgb, nseg, _, _ = oracle.probe_paths(w, rays, [1, 2, 3])
+    assert list(nseg) == [1, 1, 1]
+    assert np.allclose(rgb[0], (1, 1, 1), atol=1e-12) and np.allclose(rgb[1], (0.75, 0.85, 1), atol=1e-12)
+    # depth = 0 hit on a lambertian -> (0,0,0) after one segment
+    w2 = world_of(_dome(), r.hitable.sphere(center=vec3(0, 0, -5), radius=1.0, material=MATERIAL))
+    rgb, nseg, _, _ = oracle.probe_paths(w2, ray7(vec3(0, 0, 0), vec3(0, 0, -1)), [7], depth=0)
+    assert list(rgb[0]) == [0, 0, 0] and nseg[0] == 1
+    # a miss returns accum = black (core.clj:40-41)
+    w3 = world_of(r.hitable.sphere(center=vec3(0, 0, -5), radius=1.0, material=MATERIAL))
+    rgb, nseg, _, _ = oracle.probe_paths(w3, ray7(vec3(0, 0, 0), vec3(0, 0, 1)), [7])
+    assert list(rgb[0]) == [0, 0, 0] and nseg[0] == 1
+    # metal whose fuzzed direction ends below the surface absorbs the path (shader.clj:56): fuzz 10 makes that common
+    metal = r.shader.metal(albedo=r.texture.constant(color=vec3(1, 1, 1)), fuzz=10)
+    w4 = world_of(_dome(), r.hitable.sphere(center=vec3(0, 0, -5), radius=1.0, material=metal))
+    rays = np.tile(ray7(vec3(0, 0, 0), vec3(0, 0, -1)), (64, 1))
+    rgb, nseg, _, _ = oracle.probe_paths(w4, rays, np.arange(64))
+    absorbed = (rgb.sum(axis=1) == 0)
+    assert absorbed.any() and (~absorbed).any()
+    # total-rays <= 51 per sample with depth 50: two facing mirrors
+    mirror = r.shader.metal(albedo=r.texture.constant(color=vec3(1, 1, 1)), fuzz=0.0)
+    w5 = world_of(r.hitable.sphere(center=vec3(0, 0, -1001), radius=1000.0, material=mirror),
+                  r.hitable.sphere(center=vec3(0, 0, 1001), radius=1000.0, material=mirror))
+    rgb, nseg, _, _ = oracle.probe_paths(w5, ray7(vec3(0, 0, 0), vec3(0, 0, 1)), [9])
+    assert nseg[0] == 51 and list(rgb[0]) == [0, 0, 0]
+
+
+# ---- K14: quantiser (core.clj:52-57) ----------------------------------------------------------------------
+def test_k14_quantiser(oracle):
+    assert list(oracle.quantise([1.0, 0.25, 4.0])) == [255, 127, 255]
+    assert list(oracle.quantise([float("nan"), 0.0, 1e-9])) == [0, 0, 0]
+
+
+# ---- K15: furnace: closed lambertian albedo rho inside an emitter of radiance 1 -> sum rho^k --------------------
+def test_k15_furnace(oracle):
+    rho = 0.5
+    lam = r.shader.lambertian(albedo=r.texture.constant(color=vec3(rho, rho, rho)))
+    light = r.shader.diffuse_light(tex=r.texture.constant(color=vec3(1, 1, 1)))
+    # a diffuse ball seen from outside, lit by a uniform dome: radiance of a convex lambertian = rho exactly
+    w = world_of(r.hitable.sphere(center=vec3(0, 0, 0), radius=1000.0, material=light),
+                 r.hitable.sphere(center=vec3(0, 0, -5), radius=1.0, material=lam))
+    rays = np.tile(ray7(vec3(0, 0, 0), vec3(0, 0, -1)), (4096, 1))
+    rgb, nseg, _, _ = oracle.probe_paths(w, rays, np.arange(4096) + 100)
+    assert np.allclose(rgb, rho) and (nseg == 2).all()  # convex + uniform light: every path is exactly rho * 1
+
+
+# ---- counter stream ---------------------------------------------------------------------------------------
+def test_rng_matches_python_restatement(oracle):
+    from raytrace_clj_amd.util import draw_bits, sample_key
+    for seed, pix, s in [(0, 0, 0), (0x5EED0002, 12345, 63), ((1 << 64) - 1, (1 << 40) + 3, 4095)]:
+        k = sample_key(seed, pix, s)
+        assert oracle.sample_key(seed, pix, s) == k
+        for d in (0, 1, 2, 1000):
+            z = draw_bits(k, d)
+            assert oracle.draw_bits(k, d) == z
+            assert oracle.draw(k, d) == (z >> 11) * 2.0 ** -53
+    # splitmix64 reference vector: seed 1234567 -> first outputs (public test vector of the generator)
+    from raytrace_clj_amd.util import SplitMix64
+    g = SplitMix64(1234567)
+    assert [g.next_u64() for _ in range(3)] == [6457827717110365317, 3203168211198807973, 9817491932198370423]
+
+
+def test_rng_uniformity(oracle):
+    k = oracle.sample_key(1, 2, 3)
+    x = np.array([oracle.draw(k, d) for d in range(20000)])
+    assert 0 <= x.min() and x.max() < 1 and abs(x.mean() - 0.5) < 0.01 and abs(x.var() - 1 / 12) < 0.005
+
+
+# ---- BVH (hitable.clj:97-123) gives the same closest hit as the Hitlist scan --------------------
+def test_bvh_equals_flat_scan(oracle, cover11_moving):
+    w = fl.flatten(cover11_moving)
+    rng = np.random.default_rng(5)
+    n = 3000
+    o = np.tile(vec3(13, 2, 3), (n, 1)) + rng.normal(0, 0.5, (n, 3))
+    d = -o + rng.normal(0, 3.0, (n, 3))
+    rays = np.concatenate([o, d, rng.random((n, 1))], axis=1)
+    flat = oracle.probe_hit(w, rays)
+    for seed in (1, 2):
+        assert np.array_equal(flat, oracle.probe_hit(w, rays, bvh_seed=seed))
+
+
+# ---- pixel/render plumbing (core.clj:43-57, 100-108) --------------------------------------------------------
+def test_render_region_and_threads(oracle, cover_small):
+    w = fl.flatten(cover_small)
+    full, q, cnt = oracle.render(w, 32, 16, 3, depth=50, seed=77)
+    assert full.shape == (16, 32, 3) and cnt[1] == 512 and 512 * 3 <= cnt[0] <= 512 * 3 * 51
+    part, qp, _ = oracle.render(w, 32, 16, 3, depth=50, seed=77, region=(8, 4, 24, 12))
+    assert np.array_equal(part, full[4:12, 8:24]) and np.array_equal(qp, q[4:12, 8:24])
+    mt, qm, cm = oracle.render(w, 32, 16, 3, depth=50, seed=77, nthreads=4)
+    assert np.array_equal(mt, full) and np.array_equal(qm, q) and cm[0] == cnt[0]
+    other, _, _ = oracle.render(w, 32, 16, 3, depth=50, seed=78)
+    assert not np.array_equal(other, full)
+    # row 0 is the TOP of the picture: sky (bright, blue-ish) above ground
+    assert full[0].mean() > 0.3
