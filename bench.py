@@ -36,7 +36,7 @@ def cpu_baseline(flat, nx, ny, ns, budget_s=12.0):
     cores on a bounded sample of the same workload: evenly spread 2-row bands of the frame at full spp."""
     from oracle.oracle import Oracle
     orc = Oracle("f64")
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     bands = [(0, y, nx, y + 2) for y in range(ny // 20, ny - 1, max(2, ny // 10))]
     t0 = time.time()
     orc.render(flat, nx, ny, min(ns, 4), 50, 0x5EED0002, region=bands[len(bands) // 2], nthreads=cores)
@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--scan-variant", type=int, default=-1, help="0 LDS literal, 1 LDS pipelined, 2 SGPR (default: library default)")
     args = ap.parse_args()
 
     import torch
@@ -89,6 +90,8 @@ def main():
     ctx = r.Context(local_rank, timing=True)
     if args.blocks_per_cu:
         ctx.set_option("blocks_per_cu", args.blocks_per_cu)
+    if args.scan_variant >= 0:
+        ctx.set_option("scan_variant", args.scan_variant)
     ds = r.DeviceScene(flat, ctx=ctx)
     tr = rdist.TileRenderer(ds, nx, ny, rank, world)
 

@@ -5,8 +5,17 @@ import os
 
 import numpy as np
 
+# PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7, + its own HSA runtime).
+# Two HIP runtimes in one process cannot both own the GPU ("No HIP GPUs are available"), so when torch is the
+# process's device-memory/stream/collective plumbing it must be loaded FIRST: librtmi.so's NEEDED libamdhip64.so.7
+# then binds to the runtime that is already mapped.  (A torch-free host, e.g. the JVM via JNA, gets /opt/rocm's.)
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover - torch-free host
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librtmi.so")
+LIB_PATH = os.environ.get("RTMI_LIB") or os.path.join(_HERE, "lib", "librtmi.so")  # RTMI_LIB: experiment builds
 
 # every symbol include/rtmi.h declares
 SYMBOLS = [

@@ -33,6 +33,9 @@ using namespace rtmi;
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef RTMI_MIN_WAVES
+#define RTMI_MIN_WAVES 2
+#endif
 
 struct TraceParams {
     int nx, ny, depth;
@@ -47,28 +50,36 @@ struct TraceParams {
     int n_ptiles;          // number of LDS tiles the static spheres are cut into
 };
 
+template <typename R> __device__ inline const R *stat4_of(SceneRef sc);
 // Stage static spheres [first, first+count) into LDS as {cx, cy, cz, r*r} (hitable.clj:188: (* radius radius)).
-template <typename R> __device__ inline void stage_prims(const DevScene &sc, Prim4<R> *lds, int first, int count) {
+template <typename R> __device__ inline void stage_prims(SceneRef sc, Prim4<R> *lds, int first, int count) {
     for (int i = threadIdx.x; i < count; i += blockDim.x) {
-        const double *g = sc.stat_geom + (size_t)(first + i) * 4;
+        const R *g = stat4_of<R>(sc) + (size_t)(first + i) * 4;
         Prim4<R> p;
-        p.cx = (R)g[0]; p.cy = (R)g[1]; p.cz = (R)g[2];
-        const R r = (R)g[3];
-        p.r2 = r * r;
+        p.cx = g[0]; p.cy = g[1]; p.cz = g[2]; p.r2 = g[3];
         lds[i] = p;
     }
 }
 
-// hit? of the whole world for the lane's ray (closest hit, t in (0.001, Float/MAX_VALUE), core.clj:25).
-// MULTI: the static spheres do not fit one LDS tile; every thread of the workgroup must call this.
-template <typename R, bool MULTI>
-__device__ inline void intersect_world(const DevScene &sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, const Path<R> &P,
+template <typename R> __device__ inline const R *stat4_of(SceneRef sc);
+template <> __device__ inline const double *stat4_of<double>(SceneRef sc) { return sc.stat4_d; }
+template <> __device__ inline const float *stat4_of<float>(SceneRef sc) { return sc.stat4_f; }
+
+// hit? of the whole world for the lane's ray (closest hit, t in (t-min, t-max); core.clj:25 passes 0.001, Float/MAX_VALUE).
+// MULTI (LDS variants only): the static spheres do not fit one LDS tile; every thread of the workgroup must call this.
+template <typename R, bool MULTI, int VARIANT>
+__device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, const Path<R> &P,
                                        bool active, R tmin, R tmax, R &best_t, int &best_i) {
     best_t = tmax;
     best_i = -1;
     const R a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
-    if (!MULTI) {
-        if (active) scan_static<R>(lds, sc.n_static, 0, P, a, tmin, best_t, best_i);
+    if (VARIANT == SCAN_SGPR) {
+        if (active) scan_static_pipe<R, false>(ScalarPrims<R>(stat4_of<R>(sc)), sc.n_static, 0, P, a, tmin, best_t, best_i);
+    } else if (!MULTI) {
+        if (active) {
+            if (VARIANT == SCAN_LDS_PIPE) scan_static_pipe<R, true>(LdsPrims<R>{lds}, sc.n_static, 0, P, a, tmin, best_t, best_i);
+            else scan_static<R>(lds, sc.n_static, 0, P, a, tmin, best_t, best_i);
+        }
     } else {
         for (int tile = 0; tile < n_ptiles; ++tile) {
             const int first = tile * prims_per_tile;
@@ -76,7 +87,10 @@ __device__ inline void intersect_world(const DevScene &sc, Prim4<R> *lds, int pr
             __syncthreads();
             stage_prims<R>(sc, lds, first, count);
             __syncthreads();
-            if (active) scan_static<R>(lds, count, first, P, a, tmin, best_t, best_i);
+            if (active) {
+                if (VARIANT == SCAN_LDS_PIPE) scan_static_pipe<R, true>(LdsPrims<R>{lds}, count, first, P, a, tmin, best_t, best_i);
+                else scan_static<R>(lds, count, first, P, a, tmin, best_t, best_i);
+            }
         }
     }
     if (active && sc.n_moving > 0) {
@@ -86,7 +100,7 @@ __device__ inline void intersect_world(const DevScene &sc, Prim4<R> *lds, int pr
 }
 
 // core.clj:43-51: jittered (u, v) for sample s of pixel (i, j), then the camera ray.
-template <typename R> __device__ inline void start_sample(const DevScene &sc, const TraceParams &tp, int i, int j, int s, Path<R> &P) {
+template <typename R> __device__ inline void start_sample(SceneRef sc, const TraceParams &tp, int i, int j, int s, Path<R> &P) {
     P.key = sample_key(tp.seed, (u64)j * (u64)tp.nx + (u64)i, (u64)s);
     P.ctr = 0;
     const R u = ((R)(float)i + next_uniform(P)) / (R)tp.nx;
@@ -97,15 +111,16 @@ template <typename R> __device__ inline void start_sample(const DevScene &sc, co
     P.depth = tp.depth;
 }
 
-template <typename R, bool MULTI>
-__global__ void __launch_bounds__(kBlock) trace_kernel(DevScene sc, TraceParams tp) {
+template <typename R, bool MULTI, int VARIANT>
+__global__ void __launch_bounds__(kBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
+    SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Prim4<R> *lds = reinterpret_cast<Prim4<R> *>(smem);
     unsigned *wg_next = reinterpret_cast<unsigned *>(smem + (size_t)tp.prims_per_tile * sizeof(Prim4<R>));
 
     const int lane = threadIdx.x & 63;
     if (threadIdx.x == 0) *wg_next = 0u;
-    if (!MULTI) stage_prims<R>(sc, lds, 0, sc.n_static);
+    if (!MULTI && VARIANT != SCAN_SGPR) stage_prims<R>(sc, lds, 0, sc.n_static);
     __syncthreads();
 
     // This workgroup's work list: chunks blockIdx.x, blockIdx.x + gridDim.x, ...; a chunk is one 8x8 pixel
@@ -159,7 +174,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(DevScene sc, TraceParams 
 
         // ---- one iteration of `color` for every live lane ---------------------------------------------
         R best_t; int best_i;
-        intersect_world<R, MULTI>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i);
+        intersect_world<R, MULTI, VARIANT>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i);
         if (alive) {
             ++nrays;
             if (!shade_segment<R>(sc, P, best_t, best_i, nullptr)) {
@@ -237,8 +252,9 @@ template <typename R> __device__ inline void load_ray(const double *q, Path<R> &
     P.ar = P.ag = P.ab = R(1); P.cr = P.cg = P.cb = R(0); P.key = 0; P.ctr = 0; P.depth = 0;
 }
 
-template <typename R>
-__global__ void __launch_bounds__(kBlock) probe_hit_kernel(DevScene sc, int prims_per_tile, int n_ptiles, int n, const double *rays, double tmin, double tmax, double *out) {
+template <typename R, int VARIANT>
+__global__ void __launch_bounds__(kBlock) probe_hit_kernel(ScenePtr scp, int prims_per_tile, int n_ptiles, int n, const double *rays, double tmin, double tmax, double *out) {
+    SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Prim4<R> *lds = reinterpret_cast<Prim4<R> *>(smem);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,7 +262,7 @@ __global__ void __launch_bounds__(kBlock) probe_hit_kernel(DevScene sc, int prim
     Path<R> P;
     load_ray<R>(rays + (size_t)(active ? k : 0) * 7, P);
     R best_t; int best_i;
-    intersect_world<R, true>(sc, lds, prims_per_tile, n_ptiles, P, active, (R)tmin, (R)tmax, best_t, best_i);
+    intersect_world<R, true, VARIANT>(sc, lds, prims_per_tile, n_ptiles, P, active, (R)tmin, (R)tmax, best_t, best_i);
     if (!active) return;
     double *o = out + (size_t)k * 11;
     for (int c = 0; c < 11; ++c) o[c] = 0.0;
@@ -257,9 +273,10 @@ __global__ void __launch_bounds__(kBlock) probe_hit_kernel(DevScene sc, int prim
     o[6] = h.nx; o[7] = h.ny; o[8] = h.nz; o[9] = h.u; o[10] = h.v;
 }
 
-template <typename R>
-__global__ void __launch_bounds__(kBlock) probe_paths_kernel(DevScene sc, int prims_per_tile, int n_ptiles, int n, const double *rays, const u64 *keys, u64 ctr0,
+template <typename R, int VARIANT>
+__global__ void __launch_bounds__(kBlock) probe_paths_kernel(ScenePtr scp, int prims_per_tile, int n_ptiles, int n, const double *rays, const u64 *keys, u64 ctr0,
                                                              int depth, double *out_rgb, u64 *out_nseg, double *log, int max_seg, int *out_nlog) {
+    SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Prim4<R> *lds = reinterpret_cast<Prim4<R> *>(smem);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,7 +289,7 @@ __global__ void __launch_bounds__(kBlock) probe_paths_kernel(DevScene sc, int pr
     const R tmin = R(0.001), tmax = Real<R>::tmax();
     while (__syncthreads_or(alive ? 1 : 0)) {
         R best_t; int best_i;
-        intersect_world<R, true>(sc, lds, prims_per_tile, n_ptiles, P, alive, tmin, tmax, best_t, best_i);
+        intersect_world<R, true, VARIANT>(sc, lds, prims_per_tile, n_ptiles, P, alive, tmin, tmax, best_t, best_i);
         if (alive) {
             ++nseg;
             alive = shade_segment<R>(sc, P, best_t, best_i, log ? &lg : nullptr);
@@ -285,7 +302,8 @@ __global__ void __launch_bounds__(kBlock) probe_paths_kernel(DevScene sc, int pr
     }
 }
 
-template <typename R> __global__ void probe_camera_kernel(DevScene sc, int n, const double *uv, const u64 *keys, double *out) {
+template <typename R> __global__ void probe_camera_kernel(ScenePtr scp, int n, const double *uv, const u64 *keys, double *out) {
+    SceneRef sc = *scp;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     Path<R> P;
@@ -295,7 +313,8 @@ template <typename R> __global__ void probe_camera_kernel(DevScene sc, int n, co
     o[0] = P.ox; o[1] = P.oy; o[2] = P.oz; o[3] = P.dx; o[4] = P.dy; o[5] = P.dz; o[6] = P.time; o[7] = (double)P.ctr;
 }
 
-template <typename R> __global__ void probe_texture_kernel(DevScene sc, int tex, int n, const double *uvp, double *out) {
+template <typename R> __global__ void probe_texture_kernel(ScenePtr scp, int tex, int n, const double *uvp, double *out) {
+    SceneRef sc = *scp;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const double *q = uvp + (size_t)k * 5;
@@ -306,7 +325,8 @@ template <typename R> __global__ void probe_texture_kernel(DevScene sc, int tex,
 
 // Shader.scatter (shader.clj) on an explicit hit record {p, normal, u, v}: the same scatter_emit the render kernel runs.
 template <typename R>
-__global__ void probe_scatter_kernel(DevScene sc, int mat, int n, const double *rays, const double *hits, const u64 *keys, double *out) {
+__global__ void probe_scatter_kernel(ScenePtr scp, int mat, int n, const double *rays, const double *hits, const u64 *keys, double *out) {
+    SceneRef sc = *scp;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     Path<R> P;
@@ -394,6 +414,7 @@ struct rtmi_ctx {
     int blocks_per_cu = 2;
     int64_t workspace_bytes = (int64_t)8 << 30;
     int accel = RTMI_ACCEL_FLAT;
+    int scan_variant = SCAN_SGPR;
     int max_lds_bytes = 64 * 1024 - 64; // static-sphere LDS tile budget per workgroup
     // workspace
     DevBuf samples, accum, tiles, tile_ids, counters, scratch_lin;
@@ -408,7 +429,8 @@ struct rtmi_ctx {
 struct rtmi_scene {
     uint32_t magic = 0x52545343u;
     rtmi_ctx *ctx = nullptr;
-    DevScene dev{};
+    DevScene dev{};             // host copy of the descriptor
+    ScenePtr d_dev = nullptr;   // the descriptor in HBM (what the kernels read)
     std::vector<void *> allocs;
     int n_prims = 0, n_mats = 0, n_tex = 0;
 };
@@ -513,15 +535,25 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         tp.nx = nx; tp.ny = ny; tp.depth = depth; tp.seed = seed; tp.tiles_x = tiles_x_of(nx);
         tp.n_local_tiles = n_local; tp.tile_ids = reinterpret_cast<const int *>(c->tile_ids.p);
         tp.s_begin = s_begin; tp.s_count = s_count; tp.samples = c->samples.p; tp.counters = cnt;
-        tp.prims_per_tile = ppt; tp.n_ptiles = nptiles;
+        tp.prims_per_tile = c->scan_variant == SCAN_SGPR ? 0 : ppt; tp.n_ptiles = nptiles;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if ((c->flags & RTMI_FLAG_TIMING) && c->events_used < 8192) {
             rc = next_event_pair(c, &e0, &e1);
             if (rc) return rc;
             HIP_TRY(hipEventRecord(e0, st));
         }
-        if (multi) hipLaunchKernelGGL((trace_kernel<R, true>), dim3(grid_trace), dim3(kBlock), lds_bytes, st, s->dev, tp);
-        else hipLaunchKernelGGL((trace_kernel<R, false>), dim3(grid_trace), dim3(kBlock), lds_bytes, st, s->dev, tp);
+        switch (c->scan_variant) {
+        case SCAN_SGPR:
+            hipLaunchKernelGGL((trace_kernel<R, false, SCAN_SGPR>), dim3(grid_trace), dim3(kBlock), 16, st, s->d_dev, tp);
+            break;
+        case SCAN_LDS_PIPE:
+            if (multi) hipLaunchKernelGGL((trace_kernel<R, true, SCAN_LDS_PIPE>), dim3(grid_trace), dim3(kBlock), lds_bytes, st, s->d_dev, tp);
+            else hipLaunchKernelGGL((trace_kernel<R, false, SCAN_LDS_PIPE>), dim3(grid_trace), dim3(kBlock), lds_bytes, st, s->d_dev, tp);
+            break;
+        default:
+            if (multi) hipLaunchKernelGGL((trace_kernel<R, true, SCAN_LDS_LITERAL>), dim3(grid_trace), dim3(kBlock), lds_bytes, st, s->d_dev, tp);
+            else hipLaunchKernelGGL((trace_kernel<R, false, SCAN_LDS_LITERAL>), dim3(grid_trace), dim3(kBlock), lds_bytes, st, s->d_dev, tp);
+        }
         HIP_TRY(hipGetLastError());
         if (e1) HIP_TRY(hipEventRecord(e1, st));
         const long long npx = (long long)n_local * 64;
@@ -570,6 +602,7 @@ RTMI_EXPORT int rtmi_init(int device, uint32_t flags, rtmi_ctx **out_ctx) {
     c->hbm = prop.totalGlobalMem;
     c->arch = prop.gcnArchName;
     if (const char *e = std::getenv("RTMI_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("RTMI_SCAN_VARIANT")) c->scan_variant = std::min(2, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("RTMI_LDS_TILE_BYTES")) c->max_lds_bytes = std::min(64 * 1024 - 64, std::max(1024, std::atoi(e)));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(RTMI_E_DEVICE, "hipStreamCreate failed"); }
     *out_ctx = c;
@@ -595,6 +628,7 @@ RTMI_EXPORT int rtmi_set_option(rtmi_ctx *c, const char *name, int64_t value) {
     if (!std::strcmp(name, "workspace_bytes")) { if (value < (1 << 20)) return fail(RTMI_E_ARG, "workspace_bytes must be >= 1 MiB"); c->workspace_bytes = value; return RTMI_OK; }
     if (!std::strcmp(name, "lds_tile_bytes")) { if (value < 1024 || value > 64 * 1024 - 64) return fail(RTMI_E_ARG, "lds_tile_bytes out of range"); c->max_lds_bytes = (int)value; return RTMI_OK; }
     if (!std::strcmp(name, "timing")) { if (value) c->flags |= RTMI_FLAG_TIMING; else c->flags &= ~RTMI_FLAG_TIMING; return RTMI_OK; }
+    if (!std::strcmp(name, "scan_variant")) { if (value < 0 || value > 2) return fail(RTMI_E_ARG, "scan_variant must be 0..2"); c->scan_variant = (int)value; return RTMI_OK; }
     if (!std::strcmp(name, "accel")) {
         if (value == RTMI_ACCEL_FLAT) { c->accel = (int)value; return RTMI_OK; }
         return fail(RTMI_E_UNSUPPORTED, "accel %lld is not available in this build", (long long)value);
@@ -638,7 +672,8 @@ RTMI_EXPORT int rtmi_scene_create(rtmi_ctx *c, int32_t n_prims, const int32_t *p
         if (mat_kind[m] < RTMI_MAT_LAMBERTIAN || mat_kind[m] > RTMI_MAT_DIFFUSE_LIGHT) return fail(RTMI_E_UNSUPPORTED, "material %d: kind %d unsupported on GPU path", m, mat_kind[m]);
         if (mat_kind[m] != RTMI_MAT_DIELECTRIC && (mat_tex[m] < 0 || mat_tex[m] >= n_tex)) return fail(RTMI_E_ARG, "material %d: texture index %d invalid", m, mat_tex[m]);
     }
-    std::vector<double> stat_geom, mov_geom;
+    std::vector<double> stat_geom, mov_geom, stat4_d;
+    std::vector<float> stat4_f;
     std::vector<int> stat_orig, mov_orig, pk((size_t)n_prims), pm((size_t)n_prims);
     for (int i = 0; i < n_prims; ++i) {
         const int kind = prim_kind[i];
@@ -652,6 +687,12 @@ RTMI_EXPORT int rtmi_scene_create(rtmi_ctx *c, int32_t n_prims, const int32_t *p
         } else {
             stat_geom.insert(stat_geom.end(), g, g + 4);
             stat_orig.push_back(i);
+            // {cx, cy, cz, r*r}: hitable.clj:188 (* radius radius), one IEEE multiply in the precision the kernel computes in
+            const volatile double r2d = g[3] * g[3];
+            const volatile float rf = (float)g[3];
+            const volatile float r2f = rf * rf;
+            stat4_d.insert(stat4_d.end(), {g[0], g[1], g[2], (double)r2d});
+            stat4_f.insert(stat4_f.end(), {(float)g[0], (float)g[1], (float)g[2], (float)r2f});
         }
     }
     HIP_TRY(hipSetDevice(c->device));
@@ -666,6 +707,15 @@ RTMI_EXPORT int rtmi_scene_create(rtmi_ctx *c, int32_t n_prims, const int32_t *p
     int rc = RTMI_OK;
     if (!rc) rc = upload(s, stat_geom, &d.stat_geom);
     if (!rc) rc = upload(s, stat_orig, &d.stat_orig);
+    if (!stat_orig.empty()) { // pad to round_up(n,8)+8 records with copies of the last sphere (see scan_static_pipe)
+        const size_t n4 = (stat_orig.size() + 7) / 8 * 8 + 8;
+        const double ld[4] = {stat4_d[stat4_d.size() - 4], stat4_d[stat4_d.size() - 3], stat4_d[stat4_d.size() - 2], stat4_d[stat4_d.size() - 1]};
+        const float lf[4] = {stat4_f[stat4_f.size() - 4], stat4_f[stat4_f.size() - 3], stat4_f[stat4_f.size() - 2], stat4_f[stat4_f.size() - 1]};
+        while (stat4_d.size() < n4 * 4) stat4_d.insert(stat4_d.end(), ld, ld + 4);
+        while (stat4_f.size() < n4 * 4) stat4_f.insert(stat4_f.end(), lf, lf + 4);
+    }
+    if (!rc) rc = upload(s, stat4_d, &d.stat4_d);
+    if (!rc) rc = upload(s, stat4_f, &d.stat4_f);
     if (!rc) rc = upload(s, mov_geom, &d.mov_geom);
     if (!rc) rc = upload(s, mov_orig, &d.mov_orig);
     if (!rc) rc = upload(s, pk, &d.prim_kind);
@@ -676,6 +726,12 @@ RTMI_EXPORT int rtmi_scene_create(rtmi_ctx *c, int32_t n_prims, const int32_t *p
     if (!rc) rc = upload(s, tk, &d.tex_kind);
     if (!rc) rc = upload(s, tpv, &d.tex_param);
     if (!rc) rc = upload(s, tc, &d.tex_child);
+    if (!rc) {
+        std::vector<DevScene> one(1, d);
+        const DevScene *dp = nullptr;
+        rc = upload(s, one, &dp);
+        s->d_dev = (ScenePtr)dp;
+    }
     if (rc) { rtmi_scene_destroy(s); return rc; }
     *out_scene = s;
     return RTMI_OK;
@@ -819,10 +875,18 @@ RTMI_EXPORT int rtmi_probe_hit(rtmi_scene *s, int32_t precision, int32_t n, cons
     int ppt, npt; size_t lds;
     if (precision == RTMI_F64) {
         lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
-        hipLaunchKernelGGL((probe_hit_kernel<double>), dim3(grid), dim3(kBlock), lds, c->stream, s->dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
+        switch (c->scan_variant) {
+        case SCAN_SGPR: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_SGPR>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
+        case SCAN_LDS_PIPE: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_LDS_PIPE>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
+        default: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_LDS_LITERAL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
+        }
     } else {
         lds_plan(c, s->dev.n_static, sizeof(float), &ppt, &npt, &lds);
-        hipLaunchKernelGGL((probe_hit_kernel<float>), dim3(grid), dim3(kBlock), lds, c->stream, s->dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
+        switch (c->scan_variant) {
+        case SCAN_SGPR: hipLaunchKernelGGL((probe_hit_kernel<float, SCAN_SGPR>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
+        case SCAN_LDS_PIPE: hipLaunchKernelGGL((probe_hit_kernel<float, SCAN_LDS_PIPE>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
+        default: hipLaunchKernelGGL((probe_hit_kernel<float, SCAN_LDS_LITERAL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
+        }
     }
     PROBE_EPILOGUE()
     HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 11 * sizeof(double), hipMemcpyDeviceToHost));
@@ -846,10 +910,18 @@ RTMI_EXPORT int rtmi_probe_paths(rtmi_scene *s, int32_t precision, int32_t n, co
     int ppt, npt; size_t lds;
     if (precision == RTMI_F64) {
         lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
-        hipLaunchKernelGGL((probe_paths_kernel<double>), dim3(grid), dim3(kBlock), lds, c->stream, s->dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
+        switch (c->scan_variant) {
+        case SCAN_SGPR: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_SGPR>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
+        case SCAN_LDS_PIPE: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_LDS_PIPE>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
+        default: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_LDS_LITERAL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
+        }
     } else {
         lds_plan(c, s->dev.n_static, sizeof(float), &ppt, &npt, &lds);
-        hipLaunchKernelGGL((probe_paths_kernel<float>), dim3(grid), dim3(kBlock), lds, c->stream, s->dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
+        switch (c->scan_variant) {
+        case SCAN_SGPR: hipLaunchKernelGGL((probe_paths_kernel<float, SCAN_SGPR>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
+        case SCAN_LDS_PIPE: hipLaunchKernelGGL((probe_paths_kernel<float, SCAN_LDS_PIPE>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
+        default: hipLaunchKernelGGL((probe_paths_kernel<float, SCAN_LDS_LITERAL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
+        }
     }
     PROBE_EPILOGUE()
     HIP_TRY(hipMemcpy(out_rgb, d_rgb, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
@@ -866,8 +938,8 @@ RTMI_EXPORT int rtmi_probe_camera(rtmi_scene *s, int32_t precision, int32_t n, c
     u64 *d_keys = (u64 *)tmp.up(keys, (size_t)n * sizeof(u64));
     double *d_out = (double *)tmp.alloc((size_t)n * 8 * sizeof(double));
     if (!d_uv || !d_keys || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
-    if (precision == RTMI_F64) hipLaunchKernelGGL((probe_camera_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, s->dev, n, d_uv, d_keys, d_out);
-    else hipLaunchKernelGGL((probe_camera_kernel<float>), dim3(grid), dim3(kBlock), 0, c->stream, s->dev, n, d_uv, d_keys, d_out);
+    if (precision == RTMI_F64) hipLaunchKernelGGL((probe_camera_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, n, d_uv, d_keys, d_out);
+    else hipLaunchKernelGGL((probe_camera_kernel<float>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, n, d_uv, d_keys, d_out);
     PROBE_EPILOGUE()
     HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 8 * sizeof(double), hipMemcpyDeviceToHost));
     return RTMI_OK;
@@ -880,8 +952,8 @@ RTMI_EXPORT int rtmi_probe_texture(rtmi_scene *s, int32_t precision, int32_t tex
     double *d_in = (double *)tmp.up(uvp, (size_t)n * 5 * sizeof(double));
     double *d_out = (double *)tmp.alloc((size_t)n * 3 * sizeof(double));
     if (!d_in || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
-    if (precision == RTMI_F64) hipLaunchKernelGGL((probe_texture_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, s->dev, tex, n, d_in, d_out);
-    else hipLaunchKernelGGL((probe_texture_kernel<float>), dim3(grid), dim3(kBlock), 0, c->stream, s->dev, tex, n, d_in, d_out);
+    if (precision == RTMI_F64) hipLaunchKernelGGL((probe_texture_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, tex, n, d_in, d_out);
+    else hipLaunchKernelGGL((probe_texture_kernel<float>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, tex, n, d_in, d_out);
     PROBE_EPILOGUE()
     HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
     return RTMI_OK;
@@ -897,8 +969,8 @@ RTMI_EXPORT int rtmi_probe_scatter(rtmi_scene *s, int32_t precision, int32_t mat
     u64 *d_keys = (u64 *)tmp.up(keys, (size_t)n * sizeof(u64));
     double *d_out = (double *)tmp.alloc((size_t)n * 9 * sizeof(double));
     if (!d_rays || !d_hits || !d_keys || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
-    if (precision == RTMI_F64) hipLaunchKernelGGL((probe_scatter_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, s->dev, mat, n, d_rays, d_hits, d_keys, d_out);
-    else hipLaunchKernelGGL((probe_scatter_kernel<float>), dim3(grid), dim3(kBlock), 0, c->stream, s->dev, mat, n, d_rays, d_hits, d_keys, d_out);
+    if (precision == RTMI_F64) hipLaunchKernelGGL((probe_scatter_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, mat, n, d_rays, d_hits, d_keys, d_out);
+    else hipLaunchKernelGGL((probe_scatter_kernel<float>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, mat, n, d_rays, d_hits, d_keys, d_out);
     PROBE_EPILOGUE()
     HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost));
     return RTMI_OK;

@@ -21,6 +21,8 @@ struct DevScene {
     int n_static;            // Sphere + UVSphere records, original relative order
     int n_moving;            // MovingSphere records
     const double *stat_geom; // [n_static][4]  cx cy cz radius
+    const double *stat4_d;   // [round_up(n_static,8)+8][4]  cx cy cz r*r (double; hitable.clj:188), padded with copies of the last
+    const float *stat4_f;    // [n_static][4]  the same, evaluated in float for RTMI_F32
     const int *stat_orig;    // [n_static] index in the caller's Hitlist
     const double *mov_geom;  // [n_moving][9]  c0.xyz radius c1.xyz t0 t1
     const int *mov_orig;
@@ -34,8 +36,12 @@ struct DevScene {
     const double *tex_param; // [n_tex][12]
     const int *tex_child;    // [n_tex][2]
     int cam_kind;
-    double cam[24];          // kernarg -> SGPRs
+    double cam[24];
 };
+// The descriptor lives in HBM and is read through the constant address space: every field access is a scalar load
+// (s_load) at its use site instead of ~80 kernarg SGPRs held live across the sphere scan.
+typedef const __attribute__((address_space(4))) DevScene &SceneRef;
+typedef const __attribute__((address_space(4))) DevScene *ScenePtr;
 
 // ---- counter-based stream: replaces clojure.core/rand (core.clj:49-50, util.clj:35-36,46-48,
 //      camera.clj:39,48, shader.clj:93); identical bits on host and device ------------------------
@@ -106,8 +112,8 @@ template <typename R> __device__ inline void rand_in_unit_disk(Path<R> &P, R &x,
 }
 
 // camera.clj:8-16 (PinholeCamera.get-ray) and camera.clj:35-48 (ThinLensCamera.get-ray)
-template <typename R> __device__ inline void get_ray(const DevScene &sc, R s, R t, Path<R> &P) {
-    const double *c = sc.cam;
+template <typename R> __device__ inline void get_ray(SceneRef sc, R s, R t, Path<R> &P) {
+    const __attribute__((address_space(4))) double *c = sc.cam;
     const R ox = (R)c[0], oy = (R)c[1], oz = (R)c[2];
     // (add lleft (mul s horiz) (mul t vert) (negate origin) ...): left fold
     R dx = (((R)c[3] + (R)c[6] * s) + (R)c[9] * t) + (-ox);
@@ -131,7 +137,7 @@ template <typename R> __device__ inline void get_ray(const DevScene &sc, R s, R 
 }
 
 // texture.clj:14-16, 26-34, 44-50 (Texture.sample); checker children are walked iteratively
-template <typename R> __device__ inline void tex_sample(const DevScene &sc, int t, R u, R v, R px, R py, R pz, R &r, R &g, R &b) {
+template <typename R> __device__ inline void tex_sample(SceneRef sc, int t, R u, R v, R px, R py, R pz, R &r, R &g, R &b) {
     r = g = b = R(0);
     for (int guard = 0; guard <= sc.n_tex; ++guard) {
         const double *tp = sc.tex_param + (size_t)t * RTMI_TEX_STRIDE;
@@ -165,6 +171,14 @@ template <typename R> struct alignas(16) Prim4 { R cx, cy, cz, r2; };
 // only (t, index) is kept per lane; p / normal / uv are rebuilt once for the winner.
 // `ok` uses strict comparisons on both ends (hitable.clj:195,203); the running t-max is the best t
 // so far (hitable.clj:20), so among equal t the first item in list order wins.
+//
+// Exact reduced quadratic.  The reference evaluates b = 2(oc.d), disc = b*b - (4a)c, t = (-b -+ sqrt(disc))/(2a).
+// Scaling by 2 and 4 commutes with IEEE rounding (no overflow/underflow at scene scales), so with
+// b' = oc.d:  disc = 4*fl(fl(b'b') - fl(a c)) = 4 disc',  sqrt(disc) = 2 sqrt(disc'),  t = fl((-b' -+ sqrt(disc'))/a)
+// bit for bit.  The kernels evaluate the primed form (two multiplies fewer per test); scan variant 0 keeps the
+// literal form so the parity tests can compare the two on the device.
+enum { SCAN_LDS_LITERAL = 0, SCAN_LDS_PIPE = 1, SCAN_SGPR = 2 };
+
 template <typename R>
 __device__ inline void scan_static(const Prim4<R> *__restrict__ lds, int n, int idx_base, const Path<R> &P, R a, R tmin, R &best_t, int &best_i) {
     const R a2 = R(2.0) * a, a4 = R(4.0) * a;
@@ -188,10 +202,97 @@ __device__ inline void scan_static(const Prim4<R> *__restrict__ lds, int n, int 
     }
 }
 
+// The two roots of one sphere for the lanes whose line meets it (disc' >= 0): hitable.clj:190-207.
+// Exact early-out (only used when t-min >= 0): with the origin outside the sphere (c > 0) and the centre behind
+// the ray (b' = oc.d > 0) both roots are <= 0: -b'-sq < 0, and sq = sqrt(fl(fl(b'b') - fl(ac))) <= sqrt(fl(b'b')) = b'
+// (a correctly rounded sqrt of a correctly rounded square returns |x|), so -b'+sq <= 0: `t > t-min` fails for both.
+template <typename R>
+__device__ inline void sphere_roots(R bq, R cq, R disc, R a, R tmin, bool behind_ok, R &best_t, int &best_i, int idx) {
+    if (behind_ok && bq > R(0) && cq > R(0)) return;
+    const R sq = Real<R>::sqrt_(disc);
+    R t = (-bq - sq) / a;
+    bool ok = (t > tmin) && (t < best_t);
+    if (!ok) {
+        t = (-bq + sq) / a;
+        ok = (t > tmin) && (t < best_t);
+    }
+    if (ok) { best_t = t; best_i = idx; }
+}
+
+template <typename R> __device__ inline void sphere_test(const Prim4<R> &s, const Path<R> &P, R a, R &bq, R &cq, R &disc) {
+    const R ocx = P.ox - s.cx, ocy = P.oy - s.cy, ocz = P.oz - s.cz;
+    bq = dot3(ocx, ocy, ocz, P.dx, P.dy, P.dz);
+    cq = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - s.r2;
+    disc = bq * bq - a * cq;
+}
+
+// Sphere data sources: LDS (per-lane VGPR copies of a broadcast read) or the scalar data cache (wave-uniform
+// SGPRs: constant address space + uniform index -> s_load_dwordx8 / x4).
+template <typename R> struct LdsPrims {
+    const Prim4<R> *p;
+    __device__ inline Prim4<R> operator()(int i) const { return p[i]; }
+};
+template <typename R> struct ScalarPrims {
+    typedef R v4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) v4 *cptr;
+    cptr p;
+    __device__ explicit ScalarPrims(const R *g) : p((cptr)(g)) {}
+    __device__ inline Prim4<R> operator()(int i) const {
+        const v4 v = p[i];
+        Prim4<R> s; s.cx = v.x; s.cy = v.y; s.cz = v.z; s.r2 = v.w;
+        return s;
+    }
+};
+
+// Software-pipelined scan: 4 spheres per group, two groups per trip in ping-pong registers, so the loads of the next
+// group are in flight while the current group's 4 x 17 independent VALU ops issue; one wave-level branch per group
+// guards the rare root computations.  The source must be readable up to index round_up(n,8)+7 (LDS: indices are
+// clamped; HBM arrays are padded with copies of the last sphere): a duplicate of the last sphere can never win
+// (strict t < best_t) and is reported under the last sphere's index.
+template <typename R> struct Group4 { Prim4<R> s0, s1, s2, s3; };
+
+template <typename R, bool CLAMP, typename Src> __device__ inline Group4<R> load_group(const Src &src, int g, int last) {
+    Group4<R> G;
+    G.s0 = src(CLAMP ? min(g, last) : g);
+    G.s1 = src(CLAMP ? min(g + 1, last) : g + 1);
+    G.s2 = src(CLAMP ? min(g + 2, last) : g + 2);
+    G.s3 = src(CLAMP ? min(g + 3, last) : g + 3);
+    return G;
+}
+
+template <typename R>
+__device__ inline void test_group(const Group4<R> &G, int g, int last, int idx_base, const Path<R> &P, R a, R tmin, bool behind_ok, R &best_t, int &best_i) {
+    R b0, q0, d0, b1, q1, d1, b2, q2, d2, b3, q3, d3;
+    sphere_test(G.s0, P, a, b0, q0, d0);
+    sphere_test(G.s1, P, a, b1, q1, d1);
+    sphere_test(G.s2, P, a, b2, q2, d2);
+    sphere_test(G.s3, P, a, b3, q3, d3);
+    if ((d0 >= R(0)) | (d1 >= R(0)) | (d2 >= R(0)) | (d3 >= R(0))) {
+        if (d0 >= R(0)) sphere_roots(b0, q0, d0, a, tmin, behind_ok, best_t, best_i, idx_base + min(g, last));
+        if (d1 >= R(0)) sphere_roots(b1, q1, d1, a, tmin, behind_ok, best_t, best_i, idx_base + min(g + 1, last));
+        if (d2 >= R(0)) sphere_roots(b2, q2, d2, a, tmin, behind_ok, best_t, best_i, idx_base + min(g + 2, last));
+        if (d3 >= R(0)) sphere_roots(b3, q3, d3, a, tmin, behind_ok, best_t, best_i, idx_base + min(g + 3, last));
+    }
+}
+
+template <typename R, bool CLAMP, typename Src>
+__device__ inline void scan_static_pipe(const Src &src, int n, int idx_base, const Path<R> &P, R a, R tmin, R &best_t, int &best_i) {
+    if (n <= 0) return;
+    const int last = n - 1;
+    const bool behind_ok = tmin >= R(0);
+    Group4<R> A = load_group<R, CLAMP>(src, 0, last);
+    for (int g = 0; g < n; g += 8) {
+        const Group4<R> B = load_group<R, CLAMP>(src, g + 4, last);
+        test_group<R>(A, g, last, idx_base, P, a, tmin, behind_ok, best_t, best_i);
+        A = load_group<R, CLAMP>(src, g + 8, last);
+        test_group<R>(B, g + 4, last, idx_base, P, a, tmin, behind_ok, best_t, best_i);
+    }
+}
+
 // hitable.clj:219-252 (MovingSphere.hit?): centre = lerp(c0, c1, (time-t0)/(t1-t0)) per ray.
 // Moving spheres are scanned after the static ones, so ties are resolved by original index.
 template <typename R>
-__device__ inline void scan_moving(const DevScene &sc, const Path<R> &P, R a, R tmin, R &best_t, int &best_i, int &best_orig) {
+__device__ inline void scan_moving(SceneRef sc, const Path<R> &P, R a, R tmin, R &best_t, int &best_i, int &best_orig) {
     const R a2 = R(2.0) * a, a4 = R(4.0) * a;
     for (int m = 0; m < sc.n_moving; ++m) {
         const double *g = sc.mov_geom + (size_t)m * RTMI_PRIM_STRIDE;
@@ -226,7 +327,7 @@ template <typename R> struct HitRec { R t, px, py, pz, nx, ny, nz, u, v; int ori
 // Rebuild the hit record of scan index best_i at parameter t: centre (hitable.clj:219-222 for moving
 // spheres), p = point-at-parameter (util.clj:18-22), normal = normalise(p - centre) (hitable.clj:194),
 // uv = get-sphere-uv for UVSphere (hitable.clj:128-139) else [0 0].
-template <typename R> __device__ inline void resolve_hit(const DevScene &sc, const Path<R> &P, R t, int best_i, HitRec<R> &h) {
+template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path<R> &P, R t, int best_i, HitRec<R> &h) {
     R cx, cy, cz;
     if (best_i < sc.n_static) {
         const double *g = sc.stat_geom + (size_t)best_i * 4;
@@ -261,7 +362,7 @@ template <typename R> __device__ inline void resolve_hit(const DevScene &sc, con
 // Shader.scatter + Shader.emitted for the hit record, and the atten/accum update of core.clj:27-39.
 // Returns true when the path continues (the `recur` of core.clj:30) with P holding the scattered ray.
 // `att` (optional) receives the attenuation of a successful scatter.
-template <typename R> __device__ inline bool scatter_emit(const DevScene &sc, Path<R> &P, const HitRec<R> &h, R *att) {
+template <typename R> __device__ inline bool scatter_emit(SceneRef sc, Path<R> &P, const HitRec<R> &h, R *att) {
     const int mat = h.mat;
     const int mk = sc.mat_kind[mat];
     const R px = h.px, py = h.py, pz = h.pz, nx = h.nx, ny = h.ny, nz = h.nz;
@@ -338,7 +439,7 @@ template <typename R> __device__ inline bool scatter_emit(const DevScene &sc, Pa
 
 // One iteration of `color`'s loop after hit? has returned (core.clj:25-41).
 template <typename R>
-__device__ inline bool shade_segment(const DevScene &sc, Path<R> &P, R t, int best_i, SegLog *lg) {
+__device__ inline bool shade_segment(SceneRef sc, Path<R> &P, R t, int best_i, SegLog *lg) {
     if (best_i < 0) return false; // miss: (color) returns accum, core.clj:40-41
     HitRec<R> h;
     resolve_hit<R>(sc, P, t, best_i, h);
