@@ -1,0 +1,183 @@
+(ns raytrace-clj.gpu
+  "GPU path for the render loop of raytrace-clj.core/-main (core.clj:100-108 of the reference).
+
+  A scene built at the REPL from the reference's own records -- {:camera c :world w} as every
+  make-* function of raytrace-clj.scene returns -- is flattened into the primitive arrays of
+  include/rtmi.h and rendered by librtmi.so (HIP kernels for MI355X) through JNA.  Nothing is
+  computed on the JVM; unknown record types raise ex-info {:unsupported-on-gpu-path ...} so the
+  caller can fall back to the protocol path (raytrace-clj.core/pixel).
+
+  STATUS: written blind (no JVM/lein/JNA jar in the build container); the Python mirror in
+  raytrace_clj_amd/ exercises the same C-ABI call for call and is what the tests run."
+  (:require [clojure.core.matrix :as mat]
+            [raytrace-clj.scene :as scene])
+  (:import [com.sun.jna Function Pointer Memory]
+           [com.sun.jna.ptr PointerByReference]
+           [raytrace_clj.hitable Hitlist bvh_node Sphere UVSphere MovingSphere]
+           [raytrace_clj.shader Lambertian Metal Dielectric DiffuseLight]
+           [raytrace_clj.texture Constant UVGradient Checkerboard]
+           [raytrace_clj.camera PinholeCamera ThinLensCamera]))
+
+(mat/set-current-implementation :vectorz)
+
+;;; ---------------------------------------------------------------------------------------------
+;;; JNA plumbing: plain C functions, int return codes, rtmi_last_error for the text
+;;; ---------------------------------------------------------------------------------------------
+
+(def ^:private lib "rtmi")
+
+(defn- cfn ^Function [name] (Function/getFunction lib name))
+
+(defn- check [rc]
+  (when-not (zero? rc)
+    (throw (ex-info (str "rtmi error " rc ": "
+                         (.invokeString (cfn "rtmi_last_error") (object-array 0) false))
+                    {:rtmi-code rc}))))
+
+(defn- call-int [name & args]
+  (.invokeInt (cfn name) (object-array args)))
+
+;;; ---------------------------------------------------------------------------------------------
+;;; flattener: protocol extended onto the reference's records (field names as in the reference)
+;;; ---------------------------------------------------------------------------------------------
+
+(defprotocol GpuLeaves
+  (leaves [this] "the Sphere/UVSphere/MovingSphere records below this Hitable, in Hitlist order"))
+
+(extend-protocol GpuLeaves
+  Hitlist      (leaves [this] (mapcat leaves (:items this)))      ; hitable.clj:15-26
+  bvh_node     (leaves [this] (concat (leaves (:left this)) (leaves (:right this)))) ; hitable.clj:97-105
+  Sphere       (leaves [this] [this])
+  UVSphere     (leaves [this] [this])
+  MovingSphere (leaves [this] [this])
+  Object       (leaves [this] (throw (ex-info (str (type this) " is not supported on the GPU path")
+                                              {:unsupported-on-gpu-path (type this)}))))
+
+(defn- dedup-by-identity
+  "a one-item make-bvh stores the same child twice (hitable.clj:113-114)"
+  [xs]
+  (let [seen (java.util.IdentityHashMap.)]
+    (filterv #(nil? (.put seen % true)) xs)))
+
+(defn- v3 [v] [(mat/mget v 0) (mat/mget v 1) (mat/mget v 2)])
+
+(defn- intern! [table obj build]
+  ;; table: atom {:ids IdentityHashMap, :rows []}; children are interned first
+  (let [^java.util.IdentityHashMap ids (:ids @table)]
+    (or (.get ids obj)
+        (let [row (build obj)
+              id  (count (:rows @table))]
+          (.put ids obj id)
+          (swap! table update :rows conj row)
+          id))))
+
+(defn- tex-row [textures t]
+  (condp instance? t
+    Constant     {:kind 0 :param (concat (v3 (:color t)) (repeat 9 0.0)) :child [-1 -1]}
+    UVGradient   {:kind 1 :param (mapcat v3 [(:co t) (:cu t) (:cv t) (:cuv t)]) :child [-1 -1]}
+    Checkerboard (let [c0 (intern! textures (:tex0 t) (partial tex-row textures))
+                       c1 (intern! textures (:tex1 t) (partial tex-row textures))]
+                   {:kind 2 :param (cons (double (:scale t)) (repeat 11 0.0)) :child [c0 c1]})
+    (throw (ex-info (str (type t) " is not supported on the GPU path") {:unsupported-on-gpu-path (type t)}))))
+
+(defn- mat-row [textures m]
+  (let [tex (fn [t] (intern! textures t (partial tex-row textures)))]
+    (condp instance? m
+      Lambertian   {:kind 0 :tex (tex (:albedo m)) :param 0.0}
+      Metal        {:kind 1 :tex (tex (:albedo m)) :param (double (:fuzz m))}
+      Dielectric   {:kind 2 :tex -1 :param (double (:ri m))}
+      DiffuseLight {:kind 3 :tex (tex (:tex m)) :param 0.0}
+      (throw (ex-info (str (type m) " is not supported on the GPU path") {:unsupported-on-gpu-path (type m)})))))
+
+(defn- prim-row [o]
+  (condp instance? o
+    MovingSphere {:kind 2 :geom (concat (v3 (:center0 o)) [(double (:radius o))] (v3 (:center1 o))
+                                        [(double (:t0 o)) (double (:t1 o))])}
+    UVSphere     {:kind 1 :geom (concat (v3 (:center o)) [(double (:radius o))] (v3 (:center o)) [0.0 1.0])}
+    Sphere       {:kind 0 :geom (concat (v3 (:center o)) [(double (:radius o))] (v3 (:center o)) [0.0 1.0])}))
+
+(defn- camera-row [c]
+  (condp instance? c
+    ThinLensCamera {:kind 1 :cam (concat (mapcat v3 [(:origin c) (:lleft c) (:horiz c) (:vert c) (:u c) (:v c) (:w c)])
+                                         [(double (:aperture c)) (double (:t0 c)) (double (:t1 c))])}
+    PinholeCamera  {:kind 0 :cam (concat (mapcat v3 [(:origin c) (:lleft c) (:horiz c) (:vert c)]) (repeat 12 0.0))}
+    (throw (ex-info (str (type c) " is not supported on the GPU path") {:unsupported-on-gpu-path (type c)}))))
+
+(defn flatten-scene
+  "{:camera c :world w} -> the flat arrays of include/rtmi.h (as Clojure primitive arrays)"
+  [{:keys [camera world]}]
+  (let [prims     (dedup-by-identity (leaves world))
+        textures  (atom {:ids (java.util.IdentityHashMap.) :rows []})
+        materials (atom {:ids (java.util.IdentityHashMap.) :rows []})
+        prim-mat  (mapv #(intern! materials (:material %) (partial mat-row textures)) prims)
+        prows     (mapv prim-row prims)
+        mrows     (:rows @materials)
+        trows     (:rows @textures)
+        cam       (camera-row camera)]
+    {:n-prims   (count prims)
+     :prim-kind (int-array (map :kind prows))
+     :prim-geom (double-array (mapcat :geom prows))
+     :prim-mat  (int-array prim-mat)
+     :n-mats    (count mrows)
+     :mat-kind  (int-array (map :kind mrows))
+     :mat-tex   (int-array (map :tex mrows))
+     :mat-param (double-array (map :param mrows))
+     :n-tex     (count trows)
+     :tex-kind  (int-array (map :kind trows))
+     :tex-param (double-array (mapcat :param trows))
+     :tex-child (int-array (mapcat :child trows))
+     :cam-kind  (int (:kind cam))
+     :cam       (double-array (:cam cam))}))
+
+;;; ---------------------------------------------------------------------------------------------
+;;; render: replaces (dorun (cp/upmap ...)) of core.clj:100-108
+;;; ---------------------------------------------------------------------------------------------
+
+(defn render
+  "Render scene {:camera :world} at nx x ny with ns samples per pixel on GPU `device`.
+  Returns {:rgb8 byte-array (row 0 = top, RGB interleaved) :linear double-array
+           :total-rays n :total-pixels n} (the counters of metrics.clj:8-9)."
+  [scene nx ny ns & {:keys [depth seed device precision] :or {depth 50 seed 0x5eed0002 device 0 precision 0}}]
+  (let [f    (flatten-scene scene)
+        ctx  (PointerByReference.)
+        scn  (PointerByReference.)
+        npx  (* nx ny)
+        lin  (double-array (* 3 npx))
+        rgb  (byte-array (* 3 npx))
+        cnt  (long-array 2)]
+    (check (call-int "rtmi_init" (int device) (int 0) ctx))
+    (try
+      (check (call-int "rtmi_scene_create" (.getValue ctx)
+                       (int (:n-prims f)) (:prim-kind f) (:prim-geom f) (:prim-mat f)
+                       (int (:n-mats f)) (:mat-kind f) (:mat-tex f) (:mat-param f)
+                       (int (:n-tex f)) (:tex-kind f) (:tex-param f) (:tex-child f)
+                       (:cam-kind f) (:cam f) scn))
+      (try
+        (check (call-int "rtmi_render" (.getValue scn) (int nx) (int ny) (int ns) (int depth) (long seed) (int precision)
+                         (int 0) (int 0) (int nx) (int ny) lin rgb cnt))
+        {:rgb8 rgb :linear lin :total-rays (aget cnt 0) :total-pixels (aget cnt 1)}
+        (finally (call-int "rtmi_scene_destroy" (.getValue scn))))
+      (finally (call-int "rtmi_shutdown" (.getValue ctx))))))
+
+(defn save-ppm
+  "imagez `save` (core.clj:112) has no PPM writer; binary P6 written here"
+  [filename ^bytes rgb8 nx ny]
+  (with-open [o (java.io.FileOutputStream. ^String filename)]
+    (.write o (.getBytes (format "P6\n%d %d\n255\n" nx ny)))
+    (.write o rgb8)))
+
+(defn -main
+  "lein run name nx ny ns -- same positional arguments as raytrace-clj.core/-main (core.clj:73-80);
+  renders the cover scene (the commented-out line core.clj:89)."
+  [& [name ix iy is]]
+  (let [tstart   (System/currentTimeMillis)
+        filename (or name "render.ppm")
+        nx (if ix (Integer/parseUnsignedInt ix) 200)
+        ny (if iy (Integer/parseUnsignedInt iy) 100)
+        nr (if is (Integer/parseUnsignedInt is) 100)
+        {:keys [rgb8 total-rays total-pixels]} (render (scene/make-random-scene nx ny 11 true) nx ny nr)
+        elapsed (/ (- (System/currentTimeMillis) tstart) 1000.0)]
+    (println (format "%.2fs, %d%%, ETA %.2fs" elapsed 100 0.0))      ; display.clj:20-24
+    (println "total-rays" total-rays "total-pixels" total-pixels)    ; metrics.clj:8-9
+    (save-ppm filename rgb8 nx ny)
+    (println "wrote" filename)))                                     ; core.clj:113

@@ -399,25 +399,32 @@ static void pixel(const rto_scene *sc, int i, int j, int nx, int ny, int ns, int
     }
 }
 
-/* ---- the render loop (core.clj:100-108): rows split over threads, y-flip on store ---- */
+/* ---- the render loop (core.clj:100-108): 32-pixel row-major chunks (tiled-coords, core.clj:59-71) handed to a
+ * pool of threads in no particular order (cp/upmap), y-flip on store ---- */
 typedef struct {
     const rto_scene *sc; int nx, ny, ns, depth; uint64_t seed;
     int x0, y0, x1, y1; double *lin; uint8_t *rgb8;
-    int tid, nthreads; uint64_t nrays;
+    long *next_chunk; uint64_t nrays;
 } job_t;
 
-static void *render_rows(void *arg) {
+static void *render_chunks(void *arg) {
     job_t *jb = (job_t *)arg;
-    int w = jb->x1 - jb->x0;
-    for (int y = jb->y0 + jb->tid; y < jb->y1; y += jb->nthreads) {
-        int j = jb->ny - 1 - y; /* core.clj:105: set-pixel image i (- (dec ny) j) */
-        for (int x = jb->x0; x < jb->x1; ++x) {
+    const int w = jb->x1 - jb->x0;
+    const long npix = (long)w * (jb->y1 - jb->y0);
+    for (;;) {
+        long c = __atomic_fetch_add(jb->next_chunk, 1, __ATOMIC_RELAXED);
+        long first = c * 32;
+        if (first >= npix) break;
+        long lastp = first + 32 < npix ? first + 32 : npix;
+        for (long k = first; k < lastp; ++k) {
+            int x = jb->x0 + (int)(k % w), y = jb->y0 + (int)(k / w);
+            int j = jb->ny - 1 - y; /* core.clj:105: set-pixel image i (- (dec ny) j) */
             real mean[3]; uint8_t q[3];
             pixel(jb->sc, x, j, jb->nx, jb->ny, jb->ns, jb->depth, jb->seed, mean, q, &jb->nrays);
-            size_t o = ((size_t)(y - jb->y0) * w + (x - jb->x0)) * 3;
-            for (int k = 0; k < 3; ++k) {
-                if (jb->lin) jb->lin[o + k] = (double)mean[k];
-                if (jb->rgb8) jb->rgb8[o + k] = q[k];
+            size_t o = (size_t)k * 3;
+            for (int ch = 0; ch < 3; ++ch) {
+                if (jb->lin) jb->lin[o + ch] = (double)mean[ch];
+                if (jb->rgb8) jb->rgb8[o + ch] = q[ch];
             }
         }
     }
@@ -432,13 +439,14 @@ RTO_API int rto_render(const rto_scene *sc, int nx, int ny, int ns, int depth, u
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
     job_t jobs[256]; pthread_t th[256];
+    long next_chunk = 0;
     for (int t = 0; t < nthreads; ++t) {
-        job_t jb = {sc, nx, ny, ns, depth, seed, x0, y0, x1, y1, out_linear, out_rgb8, t, nthreads, 0};
+        job_t jb = {sc, nx, ny, ns, depth, seed, x0, y0, x1, y1, out_linear, out_rgb8, &next_chunk, 0};
         jobs[t] = jb;
     }
-    if (nthreads == 1) render_rows(&jobs[0]);
+    if (nthreads == 1) render_chunks(&jobs[0]);
     else {
-        for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, render_rows, &jobs[t]);
+        for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, render_chunks, &jobs[t]);
         for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
     }
     if (counters) {

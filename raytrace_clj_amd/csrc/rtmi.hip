@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -34,7 +35,7 @@ namespace {
 
 constexpr int kBlock = 256;
 #ifndef RTMI_MIN_WAVES
-#define RTMI_MIN_WAVES 2
+#define RTMI_MIN_WAVES 4
 #endif
 
 struct TraceParams {
@@ -65,6 +66,14 @@ template <typename R> __device__ inline const R *stat4_of(SceneRef sc);
 template <> __device__ inline const double *stat4_of<double>(SceneRef sc) { return sc.stat4_d; }
 template <> __device__ inline const float *stat4_of<float>(SceneRef sc) { return sc.stat4_f; }
 
+// the FP32 cull exists for the FP64 path only; RTMI_F32 falls back to the plain scalar-cache scan
+__device__ inline void scan_cull_dispatch(SceneRef sc, const Path<double> &P, double a, double tmin, double &best_t, int &best_i) {
+    scan_static_cull(sc.cull20, sc.stat4_d, sc.n_static, P, a, tmin, best_t, best_i);
+}
+__device__ inline void scan_cull_dispatch(SceneRef sc, const Path<float> &P, float a, float tmin, float &best_t, int &best_i) {
+    scan_static_pipe<float, false>(ScalarPrims<float>(sc.stat4_f), sc.n_static, 0, P, a, tmin, best_t, best_i);
+}
+
 // hit? of the whole world for the lane's ray (closest hit, t in (t-min, t-max); core.clj:25 passes 0.001, Float/MAX_VALUE).
 // MULTI (LDS variants only): the static spheres do not fit one LDS tile; every thread of the workgroup must call this.
 template <typename R, bool MULTI, int VARIANT>
@@ -73,7 +82,9 @@ __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per
     best_t = tmax;
     best_i = -1;
     const R a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
-    if (VARIANT == SCAN_SGPR) {
+    if (VARIANT == SCAN_SGPR_CULL) {
+        if (active) scan_cull_dispatch(sc, P, a, tmin, best_t, best_i);
+    } else if (VARIANT == SCAN_SGPR) {
         if (active) scan_static_pipe<R, false>(ScalarPrims<R>(stat4_of<R>(sc)), sc.n_static, 0, P, a, tmin, best_t, best_i);
     } else if (!MULTI) {
         if (active) {
@@ -120,7 +131,7 @@ __global__ void __launch_bounds__(kBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr 
 
     const int lane = threadIdx.x & 63;
     if (threadIdx.x == 0) *wg_next = 0u;
-    if (!MULTI && VARIANT != SCAN_SGPR) stage_prims<R>(sc, lds, 0, sc.n_static);
+    if (!MULTI && VARIANT != SCAN_SGPR && VARIANT != SCAN_SGPR_CULL) stage_prims<R>(sc, lds, 0, sc.n_static);
     __syncthreads();
 
     // This workgroup's work list: chunks blockIdx.x, blockIdx.x + gridDim.x, ...; a chunk is one 8x8 pixel
@@ -411,10 +422,10 @@ struct rtmi_ctx {
     int lds_per_cu = 0;
     size_t hbm = 0;
     std::string arch;
-    int blocks_per_cu = 2;
+    int blocks_per_cu = 4;
     int64_t workspace_bytes = (int64_t)8 << 30;
     int accel = RTMI_ACCEL_FLAT;
-    int scan_variant = SCAN_SGPR;
+    int scan_variant = SCAN_SGPR_CULL;
     int max_lds_bytes = 64 * 1024 - 64; // static-sphere LDS tile budget per workgroup
     // workspace
     DevBuf samples, accum, tiles, tile_ids, counters, scratch_lin;
@@ -535,7 +546,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         tp.nx = nx; tp.ny = ny; tp.depth = depth; tp.seed = seed; tp.tiles_x = tiles_x_of(nx);
         tp.n_local_tiles = n_local; tp.tile_ids = reinterpret_cast<const int *>(c->tile_ids.p);
         tp.s_begin = s_begin; tp.s_count = s_count; tp.samples = c->samples.p; tp.counters = cnt;
-        tp.prims_per_tile = c->scan_variant == SCAN_SGPR ? 0 : ppt; tp.n_ptiles = nptiles;
+        tp.prims_per_tile = c->scan_variant >= SCAN_SGPR ? 0 : ppt; tp.n_ptiles = nptiles;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if ((c->flags & RTMI_FLAG_TIMING) && c->events_used < 8192) {
             rc = next_event_pair(c, &e0, &e1);
@@ -543,6 +554,9 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             HIP_TRY(hipEventRecord(e0, st));
         }
         switch (c->scan_variant) {
+        case SCAN_SGPR_CULL:
+            hipLaunchKernelGGL((trace_kernel<R, false, SCAN_SGPR_CULL>), dim3(grid_trace), dim3(kBlock), 16, st, s->d_dev, tp);
+            break;
         case SCAN_SGPR:
             hipLaunchKernelGGL((trace_kernel<R, false, SCAN_SGPR>), dim3(grid_trace), dim3(kBlock), 16, st, s->d_dev, tp);
             break;
@@ -602,7 +616,7 @@ RTMI_EXPORT int rtmi_init(int device, uint32_t flags, rtmi_ctx **out_ctx) {
     c->hbm = prop.totalGlobalMem;
     c->arch = prop.gcnArchName;
     if (const char *e = std::getenv("RTMI_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("RTMI_SCAN_VARIANT")) c->scan_variant = std::min(2, std::max(0, std::atoi(e)));
+    if (const char *e = std::getenv("RTMI_SCAN_VARIANT")) c->scan_variant = std::min(3, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("RTMI_LDS_TILE_BYTES")) c->max_lds_bytes = std::min(64 * 1024 - 64, std::max(1024, std::atoi(e)));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(RTMI_E_DEVICE, "hipStreamCreate failed"); }
     *out_ctx = c;
@@ -628,7 +642,7 @@ RTMI_EXPORT int rtmi_set_option(rtmi_ctx *c, const char *name, int64_t value) {
     if (!std::strcmp(name, "workspace_bytes")) { if (value < (1 << 20)) return fail(RTMI_E_ARG, "workspace_bytes must be >= 1 MiB"); c->workspace_bytes = value; return RTMI_OK; }
     if (!std::strcmp(name, "lds_tile_bytes")) { if (value < 1024 || value > 64 * 1024 - 64) return fail(RTMI_E_ARG, "lds_tile_bytes out of range"); c->max_lds_bytes = (int)value; return RTMI_OK; }
     if (!std::strcmp(name, "timing")) { if (value) c->flags |= RTMI_FLAG_TIMING; else c->flags &= ~RTMI_FLAG_TIMING; return RTMI_OK; }
-    if (!std::strcmp(name, "scan_variant")) { if (value < 0 || value > 2) return fail(RTMI_E_ARG, "scan_variant must be 0..2"); c->scan_variant = (int)value; return RTMI_OK; }
+    if (!std::strcmp(name, "scan_variant")) { if (value < 0 || value > 3) return fail(RTMI_E_ARG, "scan_variant must be 0..3"); c->scan_variant = (int)value; return RTMI_OK; }
     if (!std::strcmp(name, "accel")) {
         if (value == RTMI_ACCEL_FLAT) { c->accel = (int)value; return RTMI_OK; }
         return fail(RTMI_E_UNSUPPORTED, "accel %lld is not available in this build", (long long)value);
@@ -714,6 +728,18 @@ RTMI_EXPORT int rtmi_scene_create(rtmi_ctx *c, int32_t n_prims, const int32_t *p
         while (stat4_d.size() < n4 * 4) stat4_d.insert(stat4_d.end(), ld, ld + 4);
         while (stat4_f.size() < n4 * 4) stat4_f.insert(stat4_f.end(), lf, lf + 4);
     }
+    std::vector<float> cull20; // per group of 4 (padded) spheres: cx[4] cy[4] cz[4] r2[4] w[4], w = (2|c|_1^2 + r2) rounded up
+    for (size_t g = 0; g + 3 < stat4_d.size() / 4; g += 4) {
+        float rec[20];
+        for (int k = 0; k < 4; ++k) {
+            const double *q = &stat4_d[(g + k) * 4];
+            rec[k] = (float)q[0]; rec[4 + k] = (float)q[1]; rec[8 + k] = (float)q[2]; rec[12 + k] = (float)q[3];
+            const double cn = std::fabs(q[0]) + std::fabs(q[1]) + std::fabs(q[2]);
+            rec[16 + k] = (float)((2.0 * cn * cn + std::fabs(q[3])) * 1.0001);
+        }
+        cull20.insert(cull20.end(), rec, rec + 20);
+    }
+    if (!rc) rc = upload(s, cull20, &d.cull20);
     if (!rc) rc = upload(s, stat4_d, &d.stat4_d);
     if (!rc) rc = upload(s, stat4_f, &d.stat4_f);
     if (!rc) rc = upload(s, mov_geom, &d.mov_geom);
@@ -876,6 +902,7 @@ RTMI_EXPORT int rtmi_probe_hit(rtmi_scene *s, int32_t precision, int32_t n, cons
     if (precision == RTMI_F64) {
         lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
         switch (c->scan_variant) {
+        case SCAN_SGPR_CULL: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_SGPR_CULL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
         case SCAN_SGPR: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_SGPR>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
         case SCAN_LDS_PIPE: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_LDS_PIPE>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
         default: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_LDS_LITERAL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
@@ -883,6 +910,7 @@ RTMI_EXPORT int rtmi_probe_hit(rtmi_scene *s, int32_t precision, int32_t n, cons
     } else {
         lds_plan(c, s->dev.n_static, sizeof(float), &ppt, &npt, &lds);
         switch (c->scan_variant) {
+        case SCAN_SGPR_CULL: hipLaunchKernelGGL((probe_hit_kernel<float, SCAN_SGPR_CULL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
         case SCAN_SGPR: hipLaunchKernelGGL((probe_hit_kernel<float, SCAN_SGPR>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
         case SCAN_LDS_PIPE: hipLaunchKernelGGL((probe_hit_kernel<float, SCAN_LDS_PIPE>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
         default: hipLaunchKernelGGL((probe_hit_kernel<float, SCAN_LDS_LITERAL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
@@ -911,6 +939,7 @@ RTMI_EXPORT int rtmi_probe_paths(rtmi_scene *s, int32_t precision, int32_t n, co
     if (precision == RTMI_F64) {
         lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
         switch (c->scan_variant) {
+        case SCAN_SGPR_CULL: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_SGPR_CULL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
         case SCAN_SGPR: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_SGPR>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
         case SCAN_LDS_PIPE: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_LDS_PIPE>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
         default: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_LDS_LITERAL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
@@ -918,6 +947,7 @@ RTMI_EXPORT int rtmi_probe_paths(rtmi_scene *s, int32_t precision, int32_t n, co
     } else {
         lds_plan(c, s->dev.n_static, sizeof(float), &ppt, &npt, &lds);
         switch (c->scan_variant) {
+        case SCAN_SGPR_CULL: hipLaunchKernelGGL((probe_paths_kernel<float, SCAN_SGPR_CULL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
         case SCAN_SGPR: hipLaunchKernelGGL((probe_paths_kernel<float, SCAN_SGPR>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
         case SCAN_LDS_PIPE: hipLaunchKernelGGL((probe_paths_kernel<float, SCAN_LDS_PIPE>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
         default: hipLaunchKernelGGL((probe_paths_kernel<float, SCAN_LDS_LITERAL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);

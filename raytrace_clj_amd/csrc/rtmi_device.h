@@ -22,7 +22,8 @@ struct DevScene {
     int n_moving;            // MovingSphere records
     const double *stat_geom; // [n_static][4]  cx cy cz radius
     const double *stat4_d;   // [round_up(n_static,8)+8][4]  cx cy cz r*r (double; hitable.clj:188), padded with copies of the last
-    const float *stat4_f;    // [n_static][4]  the same, evaluated in float for RTMI_F32
+    const float *stat4_f;    // the same, evaluated in float for RTMI_F32
+    const float *cull20;     // [round_up(n_static,8)/4 + 2][20] per group of 4 spheres: cx[4] cy[4] cz[4] r2[4] w[4] (see CullRay)
     const int *stat_orig;    // [n_static] index in the caller's Hitlist
     const double *mov_geom;  // [n_moving][9]  c0.xyz radius c1.xyz t0 t1
     const int *mov_orig;
@@ -177,7 +178,7 @@ template <typename R> struct alignas(16) Prim4 { R cx, cy, cz, r2; };
 // b' = oc.d:  disc = 4*fl(fl(b'b') - fl(a c)) = 4 disc',  sqrt(disc) = 2 sqrt(disc'),  t = fl((-b' -+ sqrt(disc'))/a)
 // bit for bit.  The kernels evaluate the primed form (two multiplies fewer per test); scan variant 0 keeps the
 // literal form so the parity tests can compare the two on the device.
-enum { SCAN_LDS_LITERAL = 0, SCAN_LDS_PIPE = 1, SCAN_SGPR = 2 };
+enum { SCAN_LDS_LITERAL = 0, SCAN_LDS_PIPE = 1, SCAN_SGPR = 2, SCAN_SGPR_CULL = 3 };
 
 template <typename R>
 __device__ inline void scan_static(const Prim4<R> *__restrict__ lds, int n, int idx_base, const Path<R> &P, R a, R tmin, R &best_t, int &best_i) {
@@ -286,6 +287,100 @@ __device__ inline void scan_static_pipe(const Src &src, int n, int idx_base, con
         test_group<R>(A, g, last, idx_base, P, a, tmin, behind_ok, best_t, best_i);
         A = load_group<R, CLAMP>(src, g + 8, last);
         test_group<R>(B, g + 4, last, idx_base, P, a, tmin, behind_ok, best_t, best_i);
+    }
+}
+
+// ---- conservative FP32 cull in front of the exact FP64 test (scan variant SCAN_SGPR_CULL) ------------------------
+// The exact test needs 17 FP64 VALU ops per (ray, sphere) (4 SIMD cycles each on CDNA4); almost all of them only
+// establish "the line misses this sphere".  The cull evaluates the same discriminant D = (oc.d)^2 - |d|^2 (|oc|^2 - r^2)
+// in FP32 (13 ops, 2 cycles each, FMAs allowed) and rejects the sphere only when D_f + tol < 0, where tol bounds
+// |D_f - D| + |D_fp64 - D|, so a sphere whose FP64 discriminant is >= 0 is NEVER rejected and the closest hit, its t
+// and everything downstream stay bit-identical to the un-culled scan (asserted on the device by the parity tests).
+//
+// Error bound (u = 2^-24; S = |o|_1 + |c|_1 >= |oc|_2; a = |d|^2; first order, constants rounded up):
+//   inputs rounded to float:  |d(oc_k)| <= 2u(|o_k| + |c_k|)  =>  |d(oc)|_2 <= 2uS ;  |d(d)|_2 <= u|d|
+//   b = oc.d   (3 ops):        |db| <= (2+1+3) u S|d| = 6u S|d|        =>  |d(b^2)| <= 12u S^2 a
+//   q = |oc|^2 - r2 (4 ops):   |dq| <= 4uS^2 + u r2 + 4u(S^2 + r2)     =   8u S^2 + 5u r2
+//   a (conversion + 3 ops):    |da| <= 5u a
+//   a q (1 op):                |d(aq)| <= 5u a(S^2+r2) + a(8uS^2+5u r2) + u a(S^2+r2) <= 15u a(S^2 + r2)
+//   final fma:                 <= 2u a(S^2 + r2)
+//   total |D_f - D| <= 29u a(S^2 + r2); the FP64 evaluation's own error is ~2^-29 of that.
+// The kernel uses tol = 64u a_f (2|o|_1^2 + 2|c|_1^2 + r2) >= 64u a (S^2 + r2) (2x margin for second-order terms and for
+// the float evaluation of tol itself).  Rays whose float image could overflow/underflow (|o|_1 > 1e15, a outside
+// [1e-30, 1e30]) or hold NaN take tol = FLT_MAX, i.e. every sphere goes to the exact test.
+struct CullRay { float ox, oy, oz, dx, dy, dz, a, A0, A1; };
+
+__device__ inline CullRay make_cull_ray(const Path<double> &P, double a) {
+    CullRay c;
+    c.ox = (float)P.ox; c.oy = (float)P.oy; c.oz = (float)P.oz;
+    c.dx = (float)P.dx; c.dy = (float)P.dy; c.dz = (float)P.dz;
+    c.a = fmaf(c.dz, c.dz, fmaf(c.dy, c.dy, c.dx * c.dx));
+    const float on = (fabsf(c.ox) + fabsf(c.oy)) + fabsf(c.oz);
+    const float ku = 64.0f * 5.9604645e-08f; // 64 * 2^-24
+    c.A1 = ku * c.a * 1.0001f;
+    c.A0 = c.A1 * (2.0f * on * on);
+    const bool safe = (on < 1e15f) && (c.a > 1e-30f) && (c.a < 1e30f) && (a > 1e-30) && (a < 1e30);
+    if (!safe) { // NaN compares false too
+        c.ox = c.oy = c.oz = c.dx = c.dy = c.dz = 0.0f; c.a = 0.0f; c.A1 = 0.0f; c.A0 = 3.0e38f;
+    }
+    return c;
+}
+
+struct CullGroup { float cx[4], cy[4], cz[4], r2[4], w[4]; };
+
+__device__ inline CullGroup load_cull_group(const float *base, int group) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) f4 *cptr;
+    const cptr p = (cptr)(base) + (size_t)group * 5;
+    const f4 x = p[0], y = p[1], z = p[2], r = p[3], w = p[4];
+    CullGroup G;
+    G.cx[0] = x.x; G.cx[1] = x.y; G.cx[2] = x.z; G.cx[3] = x.w;
+    G.cy[0] = y.x; G.cy[1] = y.y; G.cy[2] = y.z; G.cy[3] = y.w;
+    G.cz[0] = z.x; G.cz[1] = z.y; G.cz[2] = z.z; G.cz[3] = z.w;
+    G.r2[0] = r.x; G.r2[1] = r.y; G.r2[2] = r.z; G.r2[3] = r.w;
+    G.w[0] = w.x; G.w[1] = w.y; G.w[2] = w.z; G.w[3] = w.w;
+    return G;
+}
+
+// D_f + tol for sphere k of the group (>= 0: the sphere may be hit, run the exact test)
+__device__ inline float cull_disc(const CullGroup &G, int k, const CullRay &c) {
+    const float ocx = c.ox - G.cx[k], ocy = c.oy - G.cy[k], ocz = c.oz - G.cz[k];
+    const float b = fmaf(ocz, c.dz, fmaf(ocy, c.dy, ocx * c.dx));
+    const float q = fmaf(ocz, ocz, fmaf(ocy, ocy, fmaf(ocx, ocx, -G.r2[k])));
+    const float t1 = fmaf(c.A1, G.w[k], c.A0);
+    const float t2 = fmaf(-c.a, q, t1);
+    return fmaf(b, b, t2);
+}
+
+__device__ inline void cull_test_group(const CullGroup &G, int g, int last, const double *stat4_d, const Path<double> &P, const CullRay &c,
+                                       double a, double tmin, bool behind_ok, double &best_t, int &best_i) {
+    const float d0 = cull_disc(G, 0, c), d1 = cull_disc(G, 1, c), d2 = cull_disc(G, 2, c), d3 = cull_disc(G, 3, c);
+    if (fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)) >= 0.0f) {
+        const ScalarPrims<double> exact(stat4_d);
+        const float dk[4] = {d0, d1, d2, d3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (dk[k] >= 0.0f) {
+                double bq, cq, disc;
+                sphere_test(exact(g + k), P, a, bq, cq, disc);
+                if (disc >= 0.0) sphere_roots(bq, cq, disc, a, tmin, behind_ok, best_t, best_i, min(g + k, last));
+            }
+        }
+    }
+}
+
+__device__ inline void scan_static_cull(const float *cull20, const double *stat4_d, int n, const Path<double> &P, double a, double tmin,
+                                        double &best_t, int &best_i) {
+    if (n <= 0) return;
+    const int last = n - 1;
+    const bool behind_ok = tmin >= 0.0;
+    const CullRay c = make_cull_ray(P, a);
+    CullGroup A = load_cull_group(cull20, 0);
+    for (int g = 0; g < n; g += 8) {
+        const CullGroup B = load_cull_group(cull20, (g >> 2) + 1);
+        cull_test_group(A, g, last, stat4_d, P, c, a, tmin, behind_ok, best_t, best_i);
+        A = load_cull_group(cull20, (g >> 2) + 2);
+        cull_test_group(B, g + 4, last, stat4_d, P, c, a, tmin, behind_ok, best_t, best_i);
     }
 }
 

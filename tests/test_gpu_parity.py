@@ -254,6 +254,78 @@ def test_integrator_kats_on_device():
     assert nseg[0] == 51 and list(rgb[0]) == [0, 0, 0]
 
 
+# ---- scan variants: LDS literal form (0), LDS pipelined (1), scalar-cache (2), scalar-cache + FP32 cull (3) ---------------
+def tangent_rays(f, n, seed):
+    """adversarial rays for a conservative cull: aimed at the silhouette of random spheres, perturbed by a few ulps to
+    either side, from origins near and far (discriminant ~ 0 at every magnitude)"""
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, f.n_prims, n)
+    c, rad = f.prim_geom[idx, 0:3], f.prim_geom[idx, 3]
+    o = c + rng.normal(size=(n, 3)) * (rad[:, None] * rng.choice([1.5, 4.0, 50.0, 2000.0], (n, 1)))
+    oc = c - o
+    dist = np.linalg.norm(oc, axis=1)
+    inside = dist <= rad
+    w = oc / dist[:, None]
+    tmp = rng.normal(size=(n, 3))
+    u = np.cross(w, tmp); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    sin_t = np.clip(rad / dist, 0, 1) * (1.0 + rng.choice([0.0, 1e-16, -1e-16, 3e-16, -3e-16, 1e-12, -1e-12, 1e-7, -1e-7], n))
+    cos_t = np.sqrt(np.clip(1 - sin_t ** 2, 0, 1))
+    d = (w * cos_t[:, None] + u * sin_t[:, None]) * rng.choice([1.0, 1e-3, 37.0, 1e4], (n, 1))
+    d[inside] = tmp[inside]
+    return np.concatenate([o, d, rng.random((n, 1))], axis=1)
+
+
+def test_scan_variants_are_bit_identical(oracle, cover11, cover11_moving):
+    for sc in (cover11, cover11_moving, r.scene.make_random_scene(64, 32, 50, False)):
+        f = fl.flatten(sc)
+        rays = np.concatenate([random_rays(20000, 8), tangent_rays(f, 60000, 9)])
+        ctx = core.Context(0)
+        ds = core.DeviceScene(f, ctx=ctx)
+        outs = []
+        for variant in (0, 1, 2, 3):
+            ctx.set_option("scan_variant", variant)
+            outs.append(ds.probe_hit(rays))
+        for o in outs[1:]:
+            assert np.array_equal(o, outs[0])
+        sub = rays[::7]
+        assert np.array_equal(outs[3][::7, :9], oracle.probe_hit(f, sub)[:, :9])
+        # t_min = 0 (the reference's own tests) and a negative t_min (no behind-the-origin early-out allowed)
+        for tmin in (0.0, -5.0):
+            got = []
+            for variant in (0, 3):
+                ctx.set_option("scan_variant", variant)
+                got.append(ds.probe_hit(rays[:20000], tmin, FLT_MAX))
+            assert np.array_equal(got[0], got[1])
+        winners = outs[0][20000:, 1]
+        assert len(np.unique(winners)) > min(f.n_prims, 400) * 0.5  # the tangent rays really exercise many different spheres
+        imgs = []
+        for variant in (0, 1, 2, 3):
+            ctx.set_option("scan_variant", variant)
+            imgs.append(ds.render(96, 48, 6))
+        for lin, q, cnt in imgs[1:]:
+            assert np.array_equal(lin, imgs[0][0]) and np.array_equal(q, imgs[0][1]) and np.array_equal(cnt, imgs[0][2])
+        ds.close()
+        ctx.close()
+
+
+def test_cull_handles_degenerate_rays():
+    """rays the FP32 image cannot represent (huge / tiny / zero / NaN) must fall through to the exact test"""
+    s = r.hitable.sphere(center=vec3(0, 0, 0), radius=1.0, material=MATERIAL)
+    far = r.hitable.sphere(center=vec3(1e20, 0, 0), radius=1e19, material=MATERIAL)
+    ds3 = core.DeviceScene(r.hitable.hitlist(items=[s, far]), r.camera.PinholeCamera(*(np.zeros(3),) * 4))
+    rays = np.array([ray7(vec3(0, 0, -5), vec3(0, 0, 1e-25)), ray7(vec3(0, 0, -5), vec3(0, 0, 1e25)), ray7(vec3(0, 0, -5), vec3(0, 0, 0)),
+                     ray7(vec3(0, 0, -5e18), vec3(0, 0, 1)), ray7(vec3(-1e21, 0, 0), vec3(1, 0, 0)), ray7(vec3(0, 0, -5), vec3(np.nan, 0, 1)),
+                     ray7(vec3(np.inf, 0, -5), vec3(0, 0, 1))])
+    res = {}
+    for variant in (0, 3):
+        ds3.ctx.set_option("scan_variant", variant)
+        res[variant] = ds3.probe_hit(rays, 0.0, 1e300)
+    ds3.ctx.set_option("scan_variant", 3)
+    ds3.close()
+    assert np.array_equal(res[0], res[3], equal_nan=True)
+    assert list(res[0][:5, 0]) == [1, 1, 0, 1, 1]
+
+
 # ---- whole renders ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["render_cover_n3.npz", "render_two_spheres.npz"])
 def test_render_matches_golden(name):
