@@ -68,10 +68,16 @@ template <> __device__ inline const float *stat4_of<float>(SceneRef sc) { return
 
 // the FP32 cull exists for the FP64 path only; RTMI_F32 falls back to the plain scalar-cache scan
 __device__ inline void scan_cull_dispatch(SceneRef sc, const Path<double> &P, double a, double tmin, double &best_t, int &best_i) {
-    scan_static_cull(sc.cull20, sc.stat4_d, sc.n_static, P, a, tmin, best_t, best_i);
+    scan_all_cull(sc, P, a, tmin, best_t, best_i);
 }
 __device__ inline void scan_cull_dispatch(SceneRef sc, const Path<float> &P, float a, float tmin, float &best_t, int &best_i) {
     scan_static_pipe<float, false>(ScalarPrims<float>(sc.stat4_f), sc.n_static, 0, P, a, tmin, best_t, best_i);
+    if (best_i >= 0) best_i = sc.stat_orig[best_i];
+    if (sc.n_moving > 0) {
+        int best_orig = best_i >= 0 ? best_i : 0x7fffffff, scan_i = -1;
+        scan_moving<float>(sc, P, a, tmin, best_t, scan_i, best_orig);
+        if (scan_i >= 0) best_i = best_orig;
+    }
 }
 
 // hit? of the whole world for the lane's ray (closest hit, t in (t-min, t-max); core.clj:25 passes 0.001, Float/MAX_VALUE).
@@ -82,9 +88,11 @@ __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per
     best_t = tmax;
     best_i = -1;
     const R a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
-    if (VARIANT == SCAN_SGPR_CULL) {
+    if (VARIANT == SCAN_SGPR_CULL) { // all primitives, original order; returns the original index
         if (active) scan_cull_dispatch(sc, P, a, tmin, best_t, best_i);
-    } else if (VARIANT == SCAN_SGPR) {
+        return;
+    }
+    if (VARIANT == SCAN_SGPR) {
         if (active) scan_static_pipe<R, false>(ScalarPrims<R>(stat4_of<R>(sc)), sc.n_static, 0, P, a, tmin, best_t, best_i);
     } else if (!MULTI) {
         if (active) {
@@ -104,9 +112,15 @@ __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per
             }
         }
     }
-    if (active && sc.n_moving > 0) {
-        int best_orig = best_i >= 0 ? sc.stat_orig[best_i] : 0x7fffffff;
-        scan_moving<R>(sc, P, a, tmin, best_t, best_i, best_orig);
+    // static spheres were scanned in their own (original relative) order; convert to the original index, then the
+    // moving spheres, with ties resolved by original index (first in Hitlist order wins, hitable.clj:20)
+    if (active) {
+        if (best_i >= 0) best_i = sc.stat_orig[best_i];
+        if (sc.n_moving > 0) {
+            int best_orig = best_i >= 0 ? best_i : 0x7fffffff, scan_i = -1;
+            scan_moving<R>(sc, P, a, tmin, best_t, scan_i, best_orig);
+            if (scan_i >= 0) best_i = best_orig;
+        }
     }
 }
 
@@ -728,18 +742,71 @@ RTMI_EXPORT int rtmi_scene_create(rtmi_ctx *c, int32_t n_prims, const int32_t *p
         while (stat4_d.size() < n4 * 4) stat4_d.insert(stat4_d.end(), ld, ld + 4);
         while (stat4_f.size() < n4 * 4) stat4_f.insert(stat4_f.end(), lf, lf + 4);
     }
-    std::vector<float> cull20; // per group of 4 (padded) spheres: cx[4] cy[4] cz[4] r2[4] w[4], w = (2|c|_1^2 + r2) rounded up
-    for (size_t g = 0; g + 3 < stat4_d.size() / 4; g += 4) {
+    // ---- scan variant SCAN_SGPR_CULL: all primitives in Hitlist order ----
+    // exact12[i] = c0.xyz, r*r, c1.xyz, t0, t1, moving?, 0, 0 ; cull20 = FP32 bounding data per group of 4.
+    // A MovingSphere's cull entry bounds its sweep over the camera's shutter interval [t_lo, t_hi] (rays outside that
+    // interval bypass the cull, make_cull_ray): centre = midpoint of the two extreme centres, radius = r + half the
+    // distance between them, both inflated for the float rounding of the centre.
+    const double t_lo = cam_kind == RTMI_CAM_THINLENS ? std::min(cam[22], cam[23]) : 0.0;
+    const double t_hi = cam_kind == RTMI_CAM_THINLENS ? std::max(cam[22], cam[23]) : 0.0;
+    std::vector<double> exact12;
+    std::vector<float> cull_c, cull_r2, cull_w; // per primitive: centre (3), r2, w
+    for (int i = 0; i < n_prims; ++i) {
+        const double *g = prim_geom + (size_t)i * RTMI_PRIM_STRIDE;
+        const bool moving = prim_kind[i] == RTMI_PRIM_MOVING;
+        const volatile double r2d = g[3] * g[3];
+        const double rec[12] = {g[0], g[1], g[2], (double)r2d, g[4], g[5], g[6], g[7], g[8], moving ? 1.0 : 0.0, 0.0, 0.0};
+        exact12.insert(exact12.end(), rec, rec + 12);
+        double cm[3] = {g[0], g[1], g[2]}, rb = std::fabs(g[3]);
+        bool unbounded = false;
+        if (moving) {
+            const double f0 = (t_lo - g[7]) / (g[8] - g[7]), f1 = (t_hi - g[7]) / (g[8] - g[7]);
+            if (!std::isfinite(f0) || !std::isfinite(f1)) unbounded = true;
+            else {
+                double half2 = 0.0;
+                for (int k = 0; k < 3; ++k) {
+                    const double a0 = g[k] * (1.0 - f0) + g[4 + k] * f0, a1 = g[k] * (1.0 - f1) + g[4 + k] * f1;
+                    cm[k] = 0.5 * (a0 + a1);
+                    half2 += 0.25 * (a1 - a0) * (a1 - a0);
+                }
+                rb += std::sqrt(half2) * (1.0 + 1e-9);
+            }
+        }
+        float cf[3];
+        double slack = 0.0;
+        for (int k = 0; k < 3; ++k) { cf[k] = (float)cm[k]; slack += std::fabs(cm[k] - (double)cf[k]); }
+        if (moving) rb = (rb + slack) * (1.0 + 1e-6); // the bounding sphere is defined around the FLOAT centre
+        const double r2b = moving ? rb * rb * (1.0 + 1e-6) : (double)r2d;
+        const double cn = std::fabs((double)cf[0]) + std::fabs((double)cf[1]) + std::fabs((double)cf[2]) + slack;
+        double w = (2.0 * cn * cn + r2b) * 1.0001;
+        if (unbounded || !std::isfinite(w) || w > 1e37) w = 3.0e38; // tol = inf: always passes to the exact test
+        cull_c.insert(cull_c.end(), cf, cf + 3);
+        cull_r2.push_back(unbounded ? 3.0e38f : (float)std::min(r2b * (moving ? 1.0 + 1e-6 : 1.0), 3.0e38));
+        cull_w.push_back((float)w);
+    }
+    const size_t n_pad = n_prims > 0 ? ((size_t)n_prims + 7) / 8 * 8 + 8 : 0;
+    if (n_prims > 0) {
+        const std::vector<double> last12(exact12.begin() + (size_t)(n_prims - 1) * 12, exact12.begin() + (size_t)n_prims * 12);
+        exact12.resize((size_t)n_prims * 12);
+        for (size_t i = (size_t)n_prims; i < n_pad; ++i) {
+            exact12.insert(exact12.end(), last12.begin(), last12.end());
+            cull_c.push_back(cull_c[(size_t)(n_prims - 1) * 3]); cull_c.push_back(cull_c[(size_t)(n_prims - 1) * 3 + 1]); cull_c.push_back(cull_c[(size_t)(n_prims - 1) * 3 + 2]);
+            cull_r2.push_back(cull_r2[(size_t)n_prims - 1]);
+            cull_w.push_back(cull_w[(size_t)n_prims - 1]);
+        }
+    }
+    std::vector<float> cull20; // per group of 4 (padded) primitives: cx[4] cy[4] cz[4] r2[4] w[4]
+    for (size_t g = 0; g + 3 < n_pad; g += 4) {
         float rec[20];
         for (int k = 0; k < 4; ++k) {
-            const double *q = &stat4_d[(g + k) * 4];
-            rec[k] = (float)q[0]; rec[4 + k] = (float)q[1]; rec[8 + k] = (float)q[2]; rec[12 + k] = (float)q[3];
-            const double cn = std::fabs(q[0]) + std::fabs(q[1]) + std::fabs(q[2]);
-            rec[16 + k] = (float)((2.0 * cn * cn + std::fabs(q[3])) * 1.0001);
+            rec[k] = cull_c[(g + k) * 3]; rec[4 + k] = cull_c[(g + k) * 3 + 1]; rec[8 + k] = cull_c[(g + k) * 3 + 2];
+            rec[12 + k] = cull_r2[g + k]; rec[16 + k] = cull_w[g + k];
         }
         cull20.insert(cull20.end(), rec, rec + 20);
     }
+    d.n_all = n_prims; d.cull_t_lo = t_lo; d.cull_t_hi = t_hi;
     if (!rc) rc = upload(s, cull20, &d.cull20);
+    if (!rc) rc = upload(s, exact12, &d.exact12);
     if (!rc) rc = upload(s, stat4_d, &d.stat4_d);
     if (!rc) rc = upload(s, stat4_f, &d.stat4_f);
     if (!rc) rc = upload(s, mov_geom, &d.mov_geom);

@@ -23,7 +23,12 @@ struct DevScene {
     const double *stat_geom; // [n_static][4]  cx cy cz radius
     const double *stat4_d;   // [round_up(n_static,8)+8][4]  cx cy cz r*r (double; hitable.clj:188), padded with copies of the last
     const float *stat4_f;    // the same, evaluated in float for RTMI_F32
-    const float *cull20;     // [round_up(n_static,8)/4 + 2][20] per group of 4 spheres: cx[4] cy[4] cz[4] r2[4] w[4] (see CullRay)
+    // scan variant SCAN_SGPR_CULL walks ALL primitives in the caller's Hitlist order (index = original index):
+    int n_all;               // number of primitives
+    const float *cull20;     // [round_up(n_all,8)/4 + 2][20] per group of 4: cx[4] cy[4] cz[4] r2[4] w[4] (see CullRay);
+                             // a MovingSphere is represented by a sphere bounding its sweep over [cull_t_lo, cull_t_hi]
+    const double *exact12;   // [round_up(n_all,8)+8][12] c0.xyz r*r c1.xyz t0 t1 moving? 0 0 (padded with copies of the last)
+    double cull_t_lo, cull_t_hi; // ray times the swept bounds are valid for (the camera's [t0, t1])
     const int *stat_orig;    // [n_static] index in the caller's Hitlist
     const double *mov_geom;  // [n_moving][9]  c0.xyz radius c1.xyz t0 t1
     const int *mov_orig;
@@ -310,7 +315,7 @@ __device__ inline void scan_static_pipe(const Src &src, int n, int idx_base, con
 // [1e-30, 1e30]) or hold NaN take tol = FLT_MAX, i.e. every sphere goes to the exact test.
 struct CullRay { float ox, oy, oz, dx, dy, dz, a, A0, A1; };
 
-__device__ inline CullRay make_cull_ray(const Path<double> &P, double a) {
+__device__ inline CullRay make_cull_ray(const Path<double> &P, double a, double t_lo, double t_hi) {
     CullRay c;
     c.ox = (float)P.ox; c.oy = (float)P.oy; c.oz = (float)P.oz;
     c.dx = (float)P.dx; c.dy = (float)P.dy; c.dz = (float)P.dz;
@@ -319,7 +324,7 @@ __device__ inline CullRay make_cull_ray(const Path<double> &P, double a) {
     const float ku = 64.0f * 5.9604645e-08f; // 64 * 2^-24
     c.A1 = ku * c.a * 1.0001f;
     c.A0 = c.A1 * (2.0f * on * on);
-    const bool safe = (on < 1e15f) && (c.a > 1e-30f) && (c.a < 1e30f) && (a > 1e-30) && (a < 1e30);
+    const bool safe = (on < 1e15f) && (c.a > 1e-30f) && (c.a < 1e30f) && (a > 1e-30) && (a < 1e30) && (P.time >= t_lo) && (P.time <= t_hi);
     if (!safe) { // NaN compares false too
         c.ox = c.oy = c.oz = c.dx = c.dy = c.dz = 0.0f; c.a = 0.0f; c.A1 = 0.0f; c.A0 = 3.0e38f;
     }
@@ -352,35 +357,53 @@ __device__ inline float cull_disc(const CullGroup &G, int k, const CullRay &c) {
     return fmaf(b, b, t2);
 }
 
-__device__ inline void cull_test_group(const CullGroup &G, int g, int last, const double *stat4_d, const Path<double> &P, const CullRay &c,
+// exact FP64 test of primitive i (original index) for the lanes that survived the cull: Sphere / UVSphere
+// (hitable.clj:180-207 / 141-168) or MovingSphere (hitable.clj:219-252, centre = lerp(c0, c1, (time-t0)/(t1-t0)))
+__device__ inline void exact_prim_test(const double *exact12, int i, int idx, const Path<double> &P, double a, double tmin, bool behind_ok,
+                                       double &best_t, int &best_i) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) d4 *cptr;
+    const cptr p = (cptr)(exact12) + (size_t)i * 3;
+    const d4 q0 = p[0], q2 = p[2];
+    Prim4<double> s;
+    s.cx = q0.x; s.cy = q0.y; s.cz = q0.z; s.r2 = q0.w;
+    if (q2.y != 0.0) { // moving (wave-uniform branch)
+        const d4 q1 = p[1];
+        const double t0 = q1.w, t1 = q2.x;
+        const double f = (P.time - t0) / (t1 - t0), omf = 1.0 - f;
+        s.cx = q0.x * omf + q1.x * f; s.cy = q0.y * omf + q1.y * f; s.cz = q0.z * omf + q1.z * f;
+    }
+    double bq, cq, disc;
+    sphere_test(s, P, a, bq, cq, disc);
+    if (disc >= 0.0) sphere_roots(bq, cq, disc, a, tmin, behind_ok, best_t, best_i, idx);
+}
+
+__device__ inline void cull_test_group(const CullGroup &G, int g, int last, const double *exact12, const Path<double> &P, const CullRay &c,
                                        double a, double tmin, bool behind_ok, double &best_t, int &best_i) {
     const float d0 = cull_disc(G, 0, c), d1 = cull_disc(G, 1, c), d2 = cull_disc(G, 2, c), d3 = cull_disc(G, 3, c);
     if (fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)) >= 0.0f) {
-        const ScalarPrims<double> exact(stat4_d);
-        const float dk[4] = {d0, d1, d2, d3};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (dk[k] >= 0.0f) {
-                double bq, cq, disc;
-                sphere_test(exact(g + k), P, a, bq, cq, disc);
-                if (disc >= 0.0) sphere_roots(bq, cq, disc, a, tmin, behind_ok, best_t, best_i, min(g + k, last));
-            }
-        }
+        if (d0 >= 0.0f) exact_prim_test(exact12, g, min(g, last), P, a, tmin, behind_ok, best_t, best_i);
+        if (d1 >= 0.0f) exact_prim_test(exact12, g + 1, min(g + 1, last), P, a, tmin, behind_ok, best_t, best_i);
+        if (d2 >= 0.0f) exact_prim_test(exact12, g + 2, min(g + 2, last), P, a, tmin, behind_ok, best_t, best_i);
+        if (d3 >= 0.0f) exact_prim_test(exact12, g + 3, min(g + 3, last), P, a, tmin, behind_ok, best_t, best_i);
     }
 }
 
-__device__ inline void scan_static_cull(const float *cull20, const double *stat4_d, int n, const Path<double> &P, double a, double tmin,
-                                        double &best_t, int &best_i) {
+// the culled scan over ALL primitives in Hitlist order; best_i is the ORIGINAL primitive index
+__device__ inline void scan_all_cull(SceneRef sc, const Path<double> &P, double a, double tmin, double &best_t, int &best_i) {
+    const int n = sc.n_all;
     if (n <= 0) return;
     const int last = n - 1;
     const bool behind_ok = tmin >= 0.0;
-    const CullRay c = make_cull_ray(P, a);
+    const float *cull20 = sc.cull20;
+    const double *exact12 = sc.exact12;
+    const CullRay c = make_cull_ray(P, a, sc.cull_t_lo, sc.cull_t_hi);
     CullGroup A = load_cull_group(cull20, 0);
     for (int g = 0; g < n; g += 8) {
         const CullGroup B = load_cull_group(cull20, (g >> 2) + 1);
-        cull_test_group(A, g, last, stat4_d, P, c, a, tmin, behind_ok, best_t, best_i);
+        cull_test_group(A, g, last, exact12, P, c, a, tmin, behind_ok, best_t, best_i);
         A = load_cull_group(cull20, (g >> 2) + 2);
-        cull_test_group(B, g + 4, last, stat4_d, P, c, a, tmin, behind_ok, best_t, best_i);
+        cull_test_group(B, g + 4, last, exact12, P, c, a, tmin, behind_ok, best_t, best_i);
     }
 }
 
@@ -419,22 +442,17 @@ struct SegLog { double *rec; int max_seg; int n; };
 // the hit record {:t :p :uv :normal :material} (hitable.clj:196-199) of the winning primitive
 template <typename R> struct HitRec { R t, px, py, pz, nx, ny, nz, u, v; int orig, kind, mat; };
 
-// Rebuild the hit record of scan index best_i at parameter t: centre (hitable.clj:219-222 for moving
+// Rebuild the hit record of primitive `orig` (original Hitlist index) at parameter t: centre (hitable.clj:219-222 for moving
 // spheres), p = point-at-parameter (util.clj:18-22), normal = normalise(p - centre) (hitable.clj:194),
 // uv = get-sphere-uv for UVSphere (hitable.clj:128-139) else [0 0].
-template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path<R> &P, R t, int best_i, HitRec<R> &h) {
-    R cx, cy, cz;
-    if (best_i < sc.n_static) {
-        const double *g = sc.stat_geom + (size_t)best_i * 4;
-        cx = (R)g[0]; cy = (R)g[1]; cz = (R)g[2];
-        h.orig = sc.stat_orig[best_i];
-    } else {
-        const int m = best_i - sc.n_static;
-        const double *g = sc.mov_geom + (size_t)m * RTMI_PRIM_STRIDE;
+template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path<R> &P, R t, int orig, HitRec<R> &h) {
+    const double *g = sc.exact12 + (size_t)orig * 12;
+    R cx = (R)g[0], cy = (R)g[1], cz = (R)g[2];
+    h.orig = orig;
+    if (g[9] != 0.0) { // MovingSphere: centre at the ray's time (hitable.clj:219-222)
         const R t0 = (R)g[7], t1 = (R)g[8];
         const R f = (P.time - t0) / (t1 - t0), omf = R(1.0) - f;
         cx = (R)g[0] * omf + (R)g[4] * f; cy = (R)g[1] * omf + (R)g[5] * f; cz = (R)g[2] * omf + (R)g[6] * f;
-        h.orig = sc.mov_orig[m];
     }
     h.kind = sc.prim_kind[h.orig];
     h.mat = sc.prim_mat[h.orig];
@@ -534,10 +552,10 @@ template <typename R> __device__ inline bool scatter_emit(SceneRef sc, Path<R> &
 
 // One iteration of `color`'s loop after hit? has returned (core.clj:25-41).
 template <typename R>
-__device__ inline bool shade_segment(SceneRef sc, Path<R> &P, R t, int best_i, SegLog *lg) {
-    if (best_i < 0) return false; // miss: (color) returns accum, core.clj:40-41
+__device__ inline bool shade_segment(SceneRef sc, Path<R> &P, R t, int orig, SegLog *lg) {
+    if (orig < 0) return false; // miss: (color) returns accum, core.clj:40-41
     HitRec<R> h;
-    resolve_hit<R>(sc, P, t, best_i, h);
+    resolve_hit<R>(sc, P, t, orig, h);
     const bool scat = scatter_emit<R>(sc, P, h, nullptr);
     if (lg && lg->n < lg->max_seg) {
         double *q = lg->rec + (size_t)lg->n * RTMI_SEG_REC;
