@@ -436,7 +436,7 @@ struct rtmi_ctx {
     int lds_per_cu = 0;
     size_t hbm = 0;
     std::string arch;
-    int blocks_per_cu = 4;
+    int blocks_per_cu = 8; // workgroups per CU in the persistent grid (4 resident; the rest start as others drain: shorter tail)
     int64_t workspace_bytes = (int64_t)8 << 30;
     int accel = RTMI_ACCEL_FLAT;
     int scan_variant = SCAN_SGPR_CULL;
@@ -652,7 +652,7 @@ RTMI_EXPORT int rtmi_shutdown(rtmi_ctx *c) {
 RTMI_EXPORT int rtmi_set_option(rtmi_ctx *c, const char *name, int64_t value) {
     if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
     if (!name) return fail(RTMI_E_ARG, "name is NULL");
-    if (!std::strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 8) return fail(RTMI_E_ARG, "blocks_per_cu must be 1..8"); c->blocks_per_cu = (int)value; return RTMI_OK; }
+    if (!std::strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 64) return fail(RTMI_E_ARG, "blocks_per_cu must be 1..64"); c->blocks_per_cu = (int)value; return RTMI_OK; }
     if (!std::strcmp(name, "workspace_bytes")) { if (value < (1 << 20)) return fail(RTMI_E_ARG, "workspace_bytes must be >= 1 MiB"); c->workspace_bytes = value; return RTMI_OK; }
     if (!std::strcmp(name, "lds_tile_bytes")) { if (value < 1024 || value > 64 * 1024 - 64) return fail(RTMI_E_ARG, "lds_tile_bytes out of range"); c->max_lds_bytes = (int)value; return RTMI_OK; }
     if (!std::strcmp(name, "timing")) { if (value) c->flags |= RTMI_FLAG_TIMING; else c->flags &= ~RTMI_FLAG_TIMING; return RTMI_OK; }

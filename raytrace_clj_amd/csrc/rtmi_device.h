@@ -119,7 +119,11 @@ template <typename R> __device__ inline void rand_in_unit_disk(Path<R> &P, R &x,
 
 // camera.clj:8-16 (PinholeCamera.get-ray) and camera.clj:35-48 (ThinLensCamera.get-ray)
 template <typename R> __device__ inline void get_ray(SceneRef sc, R s, R t, Path<R> &P) {
-    const __attribute__((address_space(4))) double *c = sc.cam;
+    // The camera is loop-invariant, so LICM would hoist its 24 loads out of the path loop into long-lived VGPRs (which
+    // then spill).  Laundering the address through an empty asm pins the s_loads here, at the (rare) use site.
+    unsigned long long cam_addr = (unsigned long long)(&sc.cam[0]);
+    asm volatile("" : "+s"(cam_addr));
+    const __attribute__((address_space(4))) double *c = (const __attribute__((address_space(4))) double *)cam_addr;
     const R ox = (R)c[0], oy = (R)c[1], oz = (R)c[2];
     // (add lleft (mul s horiz) (mul t vert) (negate origin) ...): left fold
     R dx = (((R)c[3] + (R)c[6] * s) + (R)c[9] * t) + (-ox);
@@ -142,6 +146,26 @@ template <typename R> __device__ inline void get_ray(SceneRef sc, R s, R t, Path
     P.time = t0 + (t1 - t0) * next_uniform(P);
 }
 
+// Sign of sin(x) without evaluating the sine (Checkerboard only needs (neg? (* sin sin sin)), texture.clj:47-48).
+// k = rint(x/pi), r = x - k*pi evaluated with a two-term pi (fma: |error| <= 2 ulp(r) + |k| 4e-32); then
+// sin(x) = (-1)^k sin(r), |r| <= pi/2 + eps, so sin(x) < 0  <=>  (k odd) xor (r < 0).  No double within |x| <= 1e5 is
+// closer than ~1e-19 to a multiple of pi (the classic worst case of double range reduction is 2^-61 relative), so
+// the sign of r is decided far above its error, and a correctly signed libm/ocml sin gives the same answer.
+// x = +-0 gives sin = +-0 (product not negative); |x| > 1e5, inf and NaN fall back to the real sin.
+template <typename R> __device__ inline int sin_sign(R x) { // -1, 0, +1
+    const R s = Real<R>::sin_(x);
+    return s < R(0) ? -1 : (s > R(0) ? 1 : 0);
+}
+template <> __device__ inline int sin_sign<double>(double x) {
+    if (x == 0.0) return 0;
+    if (!(fabs(x) <= 1.0e5)) { const double s = ::sin(x); return s < 0.0 ? -1 : (s > 0.0 ? 1 : 0); }
+    const double k = ::rint(x * 0.3183098861837907);
+    double r = ::fma(-k, 3.141592653589793, x);
+    r = ::fma(-k, 1.2246467991473532e-16, r);
+    const bool odd = ((long long)k) & 1;
+    return (odd != (r < 0.0)) ? -1 : 1;
+}
+
 // texture.clj:14-16, 26-34, 44-50 (Texture.sample); checker children are walked iteratively
 template <typename R> __device__ inline void tex_sample(SceneRef sc, int t, R u, R v, R px, R py, R pz, R &r, R &g, R &b) {
     r = g = b = R(0);
@@ -162,8 +186,9 @@ template <typename R> __device__ inline void tex_sample(SceneRef sc, int t, R u,
         }
         if (kind == RTMI_TEX_CHECKER) {
             const R scale = (R)tp[0];
-            const R sines = (Real<R>::sin_(scale * px) * Real<R>::sin_(scale * py)) * Real<R>::sin_(scale * pz);
-            t = (sines < R(0)) ? sc.tex_child[2 * t] : sc.tex_child[2 * t + 1];
+            // (neg? (ereduce * (emap sin (mul scale p)))): negative <=> no factor is zero and an odd number are negative
+            const int sx = sin_sign<R>(scale * px), sy = sin_sign<R>(scale * py), sz = sin_sign<R>(scale * pz);
+            t = (sx * sy * sz < 0) ? sc.tex_child[2 * t] : sc.tex_child[2 * t + 1];
             continue;
         }
         return;
@@ -476,70 +501,71 @@ template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path
 // Returns true when the path continues (the `recur` of core.clj:30) with P holding the scattered ray.
 // `att` (optional) receives the attenuation of a successful scatter.
 template <typename R> __device__ inline bool scatter_emit(SceneRef sc, Path<R> &P, const HitRec<R> &h, R *att) {
+    // The material switch is laid out in PHASES shared by the materials that need them (one rejection-sampler loop,
+    // one |d| normalisation, one texture evaluation per trip) instead of one inlined copy per material: the lanes of a
+    // wave hold different materials, so every copy would be executed serially.  Per lane the operations and the draw
+    // order are exactly those of the material's own scatter.
     const int mat = h.mat;
     const int mk = sc.mat_kind[mat];
     const R px = h.px, py = h.py, pz = h.pz, nx = h.nx, ny = h.ny, nz = h.nz;
+    const bool is_light = mk == RTMI_MAT_DIFFUSE_LIGHT;
+    const bool live = !is_light && P.depth > 0; // core.clj:27: (and (pos? depth) (scatter ...))
+    const bool is_lamb = live && mk == RTMI_MAT_LAMBERTIAN, is_metal = live && mk == RTMI_MAT_METAL, is_diel = live && mk == RTMI_MAT_DIELECTRIC;
     bool scat = false;
     R sdx = R(0), sdy = R(0), sdz = R(0); // scattered direction
     R atr = R(1), atg = R(1), atb = R(1);  // attenuation
-    if (mk == RTMI_MAT_DIFFUSE_LIGHT) { // shader.clj:114-119: scatter nil, emitted = sample
-        R er, eg, eb;
-        tex_sample(sc, sc.mat_tex[mat], h.u, h.v, px, py, pz, er, eg, eb);
-        P.cr = P.cr + P.ar * er; P.cg = P.cg + P.ag * eg; P.cb = P.cb + P.ab * eb; // core.clj:37-39
-    } else if (P.depth > 0) { // core.clj:27: (and (pos? depth) (scatter ...))
-        if (mk == RTMI_MAT_LAMBERTIAN) { // shader.clj:29-34
-            R rx, ry, rz;
-            rand_in_unit_sphere(P, rx, ry, rz);
-            const R tx = (px + nx) + rx, ty = (py + ny) + ry, tz = (pz + nz) + rz;
-            sdx = tx - px; sdy = ty - py; sdz = tz - pz;
-            tex_sample(sc, sc.mat_tex[mat], h.u, h.v, px, py, pz, atr, atg, atb);
-            scat = true;
-        } else if (mk == RTMI_MAT_METAL) { // shader.clj:46-57 + reflect shader.clj:6-9
-            const R fuzz = (R)sc.mat_param[mat];
-            R vx = P.dx, vy = P.dy, vz = P.dz;
-            {
-                const R len = Real<R>::sqrt_(dot3(vx, vy, vz, vx, vy, vz));
-                if (len > R(0)) { const R inv = R(1.0) / len; vx = vx * inv; vy = vy * inv; vz = vz * inv; }
-            }
-            const R k = R(2.0) * dot3(vx, vy, vz, nx, ny, nz);
-            const R rfx = vx - k * nx, rfy = vy - k * ny, rfz = vz - k * nz;
-            R rx, ry, rz;
-            rand_in_unit_sphere(P, rx, ry, rz); // drawn even when fuzz = 0
-            sdx = rfx + fuzz * rx; sdy = rfy + fuzz * ry; sdz = rfz + fuzz * rz;
-            if (dot3(sdx, sdy, sdz, nx, ny, nz) > R(0)) {
-                tex_sample(sc, sc.mat_tex[mat], h.u, h.v, px, py, pz, atr, atg, atb);
-                scat = true;
-            }
-        } else if (mk == RTMI_MAT_DIELECTRIC) { // shader.clj:76-102, refract 11-20, schlick 69-74
-            const R ri = (R)sc.mat_param[mat];
-            const R dn = dot3(P.dx, P.dy, P.dz, nx, ny, nz);
-            const R dmag = Real<R>::sqrt_(dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz));
-            R onx, ony, onz, eta, cosine;
-            if (dn > R(0)) { onx = -nx; ony = -ny; onz = -nz; eta = ri; cosine = ri * (dn / dmag); }
-            else { onx = nx; ony = ny; onz = nz; eta = R(1.0) / ri; cosine = -(dn / dmag); }
-            // refract: uv = normalise(d); dt = uv.n; disc = 1 - eta*eta*(1 - dt*dt)
-            R ux = P.dx, uy = P.dy, uz = P.dz;
-            if (dmag > R(0)) { const R inv = R(1.0) / dmag; ux = ux * inv; uy = uy * inv; uz = uz * inv; }
-            const R dt = dot3(ux, uy, uz, onx, ony, onz);
-            const R disc = R(1.0) - (eta * eta) * (R(1.0) - dt * dt);
-            // reflect(ray-direction, normal): un-normalised d, original normal
-            const R k = R(2.0) * dn;
-            const R rfx = P.dx - k * nx, rfy = P.dy - k * ny, rfz = P.dz - k * nz;
-            if (disc > R(0)) {
+
+    // phase 1 -- |d| and normalise(d): Metal (shader.clj:48) and refract (shader.clj:14) / Dielectric (shader.clj:84-88)
+    R dmag = R(0), ux = P.dx, uy = P.dy, uz = P.dz;
+    if (is_metal || is_diel) {
+        dmag = Real<R>::sqrt_(dot3(ux, uy, uz, ux, uy, uz));
+        if (dmag > R(0)) { const R inv = R(1.0) / dmag; ux = ux * inv; uy = uy * inv; uz = uz * inv; }
+    }
+    // phase 2 -- rand-in-unit-sphere: Lambertian (shader.clj:32) and Metal (shader.clj:53; drawn even when fuzz = 0)
+    R rx = R(0), ry = R(0), rz = R(0);
+    if (is_lamb || is_metal) rand_in_unit_sphere(P, rx, ry, rz);
+    // phase 3 -- directions
+    if (is_lamb) { // shader.clj:29-34: target = (p + normal) + rand; dir = target - p
+        const R tx = (px + nx) + rx, ty = (py + ny) + ry, tz = (pz + nz) + rz;
+        sdx = tx - px; sdy = ty - py; sdz = tz - pz;
+        scat = true;
+    } else if (is_metal) { // shader.clj:46-57 + reflect shader.clj:6-9
+        const R fuzz = (R)sc.mat_param[mat];
+        const R k = R(2.0) * dot3(ux, uy, uz, nx, ny, nz);
+        const R rfx = ux - k * nx, rfy = uy - k * ny, rfz = uz - k * nz;
+        sdx = rfx + fuzz * rx; sdy = rfy + fuzz * ry; sdz = rfz + fuzz * rz;
+        scat = dot3(sdx, sdy, sdz, nx, ny, nz) > R(0);
+    } else if (is_diel) { // shader.clj:76-102, refract 11-20, schlick 69-74
+        const R ri = (R)sc.mat_param[mat];
+        const R dn = dot3(P.dx, P.dy, P.dz, nx, ny, nz);
+        R onx, ony, onz, eta, cosine;
+        if (dn > R(0)) { onx = -nx; ony = -ny; onz = -nz; eta = ri; cosine = ri * (dn / dmag); }
+        else { onx = nx; ony = ny; onz = nz; eta = R(1.0) / ri; cosine = -(dn / dmag); }
+        const R dt = dot3(ux, uy, uz, onx, ony, onz);
+        const R disc = R(1.0) - (eta * eta) * (R(1.0) - dt * dt);
+        // reflect(ray-direction, normal): un-normalised d, original normal
+        const R k = R(2.0) * dn;
+        sdx = P.dx - k * nx; sdy = P.dy - k * ny; sdz = P.dz - k * nz;
+        if (disc > R(0)) {
+            R r0 = (R(1.0) - ri) / (R(1.0) + ri);
+            r0 = r0 * r0;
+            const R prob = r0 + (R(1.0) - r0) * Real<R>::pow_(R(1.0) - cosine, R(5.0));
+            if (!(next_uniform(P) < prob)) { // one draw, only when refraction is possible (shader.clj:91-93)
                 const R sq = Real<R>::sqrt_(disc);
-                const R rrx = eta * (ux - onx * dt) - onx * sq;
-                const R rry = eta * (uy - ony * dt) - ony * sq;
-                const R rrz = eta * (uz - onz * dt) - onz * sq;
-                R r0 = (R(1.0) - ri) / (R(1.0) + ri);
-                r0 = r0 * r0;
-                const R prob = r0 + (R(1.0) - r0) * Real<R>::pow_(R(1.0) - cosine, R(5.0));
-                if (next_uniform(P) < prob) { sdx = rfx; sdy = rfy; sdz = rfz; } // one draw, only when refraction is possible
-                else { sdx = rrx; sdy = rry; sdz = rrz; }
-            } else {
-                sdx = rfx; sdy = rfy; sdz = rfz;
+                sdx = eta * (ux - onx * dt) - onx * sq;
+                sdy = eta * (uy - ony * dt) - ony * sq;
+                sdz = eta * (uz - onz * dt) - onz * sq;
             }
-            scat = true;
         }
+        scat = true;
+    }
+    // phase 4 -- ONE texture evaluation: emitted of DiffuseLight (shader.clj:118-119) or the albedo of a successful
+    // Lambertian / Metal scatter (shader.clj:34,57)
+    if (is_light || is_lamb || (is_metal && scat)) {
+        R tr, tg, tb;
+        tex_sample(sc, sc.mat_tex[mat], h.u, h.v, px, py, pz, tr, tg, tb);
+        if (is_light) { P.cr = P.cr + P.ar * tr; P.cg = P.cg + P.ag * tg; P.cb = P.cb + P.ab * tb; } // core.clj:37-39
+        else { atr = tr; atg = tg; atb = tb; }
     }
     if (!scat) return false;
     if (att) { att[0] = atr; att[1] = atg; att[2] = atb; }

@@ -378,6 +378,42 @@ def test_render_region_and_errors(cover_small):
     assert not lin.any() and not q.any() and cnt[0] == 16 * 8 * 2
 
 
+# ---- RTMI_F32: the same path computed in float, against the oracle built with REAL=float --------------------------------
+def test_f32_precision_matches_f32_oracle(oracle_f32, cover11_moving):
+    f = fl.flatten(cover11_moving)
+    rays = random_rays(20000, 21)
+    ds = core.DeviceScene(f)
+    got, exp = ds.probe_hit(rays, precision="f32"), oracle_f32.probe_hit(f, rays)
+    assert np.array_equal(got[:, :9], exp[:, :9]), "f32 geometry is bit-exact too (IEEE float + - * / sqrt, no contraction)"
+    n = 4096
+    keys = np.array([sample_key(5, i, 0) for i in range(n)], np.uint64)
+    uv = np.random.default_rng(3).random((n, 2))
+    cam = oracle_f32.probe_camera(f, uv, keys)
+    assert np.array_equal(ds.probe_camera(uv, keys, precision="f32"), cam)
+    rgb, nseg, log, nlog = ds.probe_paths(cam[:, :7], keys, depth=50, ctr0=40, max_seg=10, precision="f32")
+    ergb, enseg, elog, enlog = oracle_f32.probe_paths(f, cam[:, :7], keys, depth=50, ctr0=40, max_seg=10)
+    same = (nseg == enseg)
+    assert same.mean() > 0.999  # sinf/powf (ocml vs glibc) can flip a checker sign / Schlick draw in float a little more often
+    assert np.array_equal(log[same], elog[same])
+    nx, ny, ns = 96, 48, 8
+    lin, q, cnt = ds.render(nx, ny, ns, precision="f32")
+    ds.close()
+    exp_lin, exp_q, exp_cnt = oracle_f32.render(f, nx, ny, ns, 50, 0x5EED0002, nthreads=16)
+    assert rms(lin, exp_lin) < 2e-3 and abs(int(cnt[0]) - int(exp_cnt[0])) <= 0.001 * int(exp_cnt[0])
+
+
+def test_cli_main_config0(tmp_path, oracle):
+    """BASELINE config 0: `lein run out.ppm 200 100 4` (core.clj:73-80) -> cover scene (moving, core.clj:89), PPM written here"""
+    out = tmp_path / "out.ppm"
+    assert core.main([str(out), "200", "100", "4"]) == 0
+    data = out.read_bytes()
+    assert data.startswith(b"P6\n200 100\n255\n") and len(data) == len(b"P6\n200 100\n255\n") + 200 * 100 * 3
+    img = np.frombuffer(data[len(b"P6\n200 100\n255\n"):], np.uint8).reshape(100, 200, 3)
+    sc = r.scene.make_random_scene(200, 100, 11, True)
+    _, eq, _ = oracle.render(fl.flatten(sc), 200, 100, 4, 50, 0x5EED0002, nthreads=16)
+    assert np.abs(img.astype(int) - eq.astype(int)).max() <= 1
+
+
 # ---- full BASELINE sizes: size-independent properties ----------------------------------------------------------------
 def test_full_size_properties():
     """BASELINE config 1 (800x400x64, cover scene n=11): the oracle cannot finish this in seconds, so the image is
