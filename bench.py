@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--accel", default="flat", choices=["flat", "bvh"], help="flat = Hitlist scan (hitable.clj:15-26); bvh = bvh-node descent (hitable.clj:97-123)")
     ap.add_argument("--scan-variant", type=int, default=-1, help="0 LDS literal, 1 LDS pipelined, 2 SGPR (default: library default)")
     args = ap.parse_args()
 
@@ -94,6 +95,8 @@ def main():
         ctx.set_option("blocks_per_cu", args.blocks_per_cu)
     if args.scan_variant >= 0:
         ctx.set_option("scan_variant", args.scan_variant)
+    if args.accel == "bvh":
+        ctx.set_option("accel", 1)
     ds = r.DeviceScene(flat, ctx=ctx)
     tr = rdist.TileRenderer(ds, nx, ny, rank, world)
 
@@ -143,8 +146,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "%s: %dx%dx%dspp Shirley cover scene n=%d (%d spheres%s), depth 50, thin-lens camera, "
-                                   "seeded counter RNG; tiles dealt round-robin to %d GPU(s)" % (
-                                       args.config, nx, ny, ns, n, n_prims, ", moving" if moving else "", world),
+                                   "seeded counter RNG; accel=%s; tiles dealt round-robin to %d GPU(s)" % (
+                                       args.config, nx, ny, ns, n, n_prims, ", moving" if moving else "", args.accel, world),
                        "nx": nx, "ny": ny, "ns": ns, "spheres": n_prims, "depth": 50, "segments_per_sample": round(segments / samples, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -80,6 +81,14 @@ __device__ inline void scan_cull_dispatch(SceneRef sc, const Path<float> &P, flo
     }
 }
 
+// the BVH, like the cull, exists for the FP64 path; RTMI_F32 uses the plain scan
+__device__ inline void scan_bvh_dispatch(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, double &best_t, int &best_i) {
+    scan_bvh(sc, stack, P, a, tmin, best_t, best_i);
+}
+__device__ inline void scan_bvh_dispatch(SceneRef sc, int *, const Path<float> &P, float a, float tmin, float &best_t, int &best_i) {
+    scan_cull_dispatch(sc, P, a, tmin, best_t, best_i);
+}
+
 // hit? of the whole world for the lane's ray (closest hit, t in (t-min, t-max); core.clj:25 passes 0.001, Float/MAX_VALUE).
 // MULTI (LDS variants only): the static spheres do not fit one LDS tile; every thread of the workgroup must call this.
 template <typename R, bool MULTI, int VARIANT>
@@ -88,6 +97,10 @@ __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per
     best_t = tmax;
     best_i = -1;
     const R a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
+    if (VARIANT == SCAN_BVH) { // RTMI_ACCEL_BVH; `lds` is the traversal stack
+        if (active) scan_bvh_dispatch(sc, reinterpret_cast<int *>(lds), P, a, tmin, best_t, best_i);
+        return;
+    }
     if (VARIANT == SCAN_SGPR_CULL) { // all primitives, original order; returns the original index
         if (active) scan_cull_dispatch(sc, P, a, tmin, best_t, best_i);
         return;
@@ -141,11 +154,11 @@ __global__ void __launch_bounds__(kBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr 
     SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Prim4<R> *lds = reinterpret_cast<Prim4<R> *>(smem);
-    unsigned *wg_next = reinterpret_cast<unsigned *>(smem + (size_t)tp.prims_per_tile * sizeof(Prim4<R>));
+    unsigned *wg_next = reinterpret_cast<unsigned *>(smem + (VARIANT == SCAN_BVH ? (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) : (size_t)tp.prims_per_tile * sizeof(Prim4<R>)));
 
     const int lane = threadIdx.x & 63;
     if (threadIdx.x == 0) *wg_next = 0u;
-    if (!MULTI && VARIANT != SCAN_SGPR && VARIANT != SCAN_SGPR_CULL) stage_prims<R>(sc, lds, 0, sc.n_static);
+    if (!MULTI && VARIANT < SCAN_SGPR) stage_prims<R>(sc, lds, 0, sc.n_static);
     __syncthreads();
 
     // This workgroup's work list: chunks blockIdx.x, blockIdx.x + gridDim.x, ...; a chunk is one 8x8 pixel
@@ -567,7 +580,10 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             if (rc) return rc;
             HIP_TRY(hipEventRecord(e0, st));
         }
-        switch (c->scan_variant) {
+        switch (c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant) {
+        case SCAN_BVH:
+            hipLaunchKernelGGL((trace_kernel<R, false, SCAN_BVH>), dim3(grid_trace), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, st, s->d_dev, tp);
+            break;
         case SCAN_SGPR_CULL:
             hipLaunchKernelGGL((trace_kernel<R, false, SCAN_SGPR_CULL>), dim3(grid_trace), dim3(kBlock), 16, st, s->d_dev, tp);
             break;
@@ -592,6 +608,139 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         HIP_TRY(hipGetLastError());
     }
     return RTMI_OK;
+}
+
+// ---- RTMI_ACCEL_BVH host build ----------------------------------------------------------------------------------------
+// Binned-SAH binary BVH over the primitives' boxes, one primitive per leaf, each node carrying its two children's boxes
+// (one 64-byte fetch per step).  Boxes are FLOAT, rounded outward and inflated by 2^-22 * obound (see box_hit): the
+// traversal is only a conservative filter in front of the exact FP64 sphere test, so the tree's shape affects speed, never
+// results.  Primitives whose radius is a large fraction of the scene (sky dome, ground) are kept out of the tree.
+struct BvhBox { double lo[3], hi[3]; };
+struct BvhItem { BvhBox b; double cen[3]; int idx; };
+
+inline void box_grow(BvhBox &a, const BvhBox &b) { for (int k = 0; k < 3; ++k) { a.lo[k] = std::min(a.lo[k], b.lo[k]); a.hi[k] = std::max(a.hi[k], b.hi[k]); } }
+inline BvhBox box_empty() { BvhBox b; for (int k = 0; k < 3; ++k) { b.lo[k] = 1e300; b.hi[k] = -1e300; } return b; }
+inline double box_area(const BvhBox &b) { const double x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2]; return x < 0 ? 0.0 : 2.0 * (x * y + y * z + z * x); }
+inline float f_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -INFINITY); return f; }
+inline float f_up(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, INFINITY); return f; }
+
+struct BvhBuilder {
+    std::vector<BvhItem> items;
+    std::vector<float> nodes; // 16 floats per node
+    double delta = 0.0;
+    int sah_depth = 8, max_depth = 0;
+    BvhBox bounds(int b, int e) const { BvhBox r = box_empty(); for (int i = b; i < e; ++i) box_grow(r, items[(size_t)i].b); return r; }
+    void put_box(int node, int side, const BvhBox &b) {
+        float *q = &nodes[(size_t)node * 16 + (size_t)side * 6];
+        for (int k = 0; k < 3; ++k) { q[k] = f_down(b.lo[k] - delta); q[3 + k] = f_up(b.hi[k] + delta); }
+    }
+    int build(int b, int e, int depth) { // returns the child code of the subtree over items [b, e)
+        max_depth = std::max(max_depth, depth);
+        if (e - b == 1) return ~items[(size_t)b].idx;
+        const int node = (int)(nodes.size() / 16);
+        nodes.resize(nodes.size() + 16, 0.0f);
+        // split: binned SAH on the axis of largest centroid extent; median fallback (also beyond sah_depth, to bound the stack)
+        double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
+        for (int i = b; i < e; ++i) for (int k = 0; k < 3; ++k) { clo[k] = std::min(clo[k], items[(size_t)i].cen[k]); chi[k] = std::max(chi[k], items[(size_t)i].cen[k]); }
+        int axis = 0;
+        for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+        int mid = (b + e) / 2;
+        const double ext = chi[axis] - clo[axis];
+        bool done = false;
+        if (ext > 0 && depth < sah_depth && e - b > 2) {
+            const int NB = 16;
+            BvhBox bb[NB]; int cnt[NB];
+            for (int k = 0; k < NB; ++k) { bb[k] = box_empty(); cnt[k] = 0; }
+            auto bin_of = [&](const BvhItem &it) { int q = (int)((it.cen[axis] - clo[axis]) / ext * NB); return std::min(NB - 1, std::max(0, q)); };
+            for (int i = b; i < e; ++i) { const int q = bin_of(items[(size_t)i]); box_grow(bb[q], items[(size_t)i].b); cnt[q]++; }
+            double best = 1e300; int best_k = -1;
+            BvhBox right[NB]; int rc[NB];
+            BvhBox acc = box_empty(); int n = 0;
+            for (int k = NB - 1; k > 0; --k) { box_grow(acc, bb[k]); n += cnt[k]; right[k] = acc; rc[k] = n; }
+            acc = box_empty(); n = 0;
+            for (int k = 0; k < NB - 1; ++k) {
+                box_grow(acc, bb[k]); n += cnt[k];
+                if (n == 0 || rc[k + 1] == 0) continue;
+                const double cost = box_area(acc) * n + box_area(right[k + 1]) * rc[k + 1];
+                if (cost < best) { best = cost; best_k = k; }
+            }
+            if (best_k >= 0) {
+                auto it = std::partition(items.begin() + b, items.begin() + e, [&](const BvhItem &x) { return bin_of(x) <= best_k; });
+                mid = (int)(it - items.begin());
+                done = mid > b && mid < e;
+            }
+        }
+        if (!done) {
+            mid = (b + e) / 2;
+            std::nth_element(items.begin() + b, items.begin() + mid, items.begin() + e,
+                             [&](const BvhItem &x, const BvhItem &y) { return x.cen[axis] < y.cen[axis] || (x.cen[axis] == y.cen[axis] && x.idx < y.idx); });
+        }
+        const BvhBox lb = bounds(b, mid), rb = bounds(mid, e);
+        const int l = build(b, mid, depth + 1);
+        const int r = build(mid, e, depth + 1);
+        put_box(node, 0, lb);
+        put_box(node, 1, rb);
+        std::memcpy(&nodes[(size_t)node * 16 + 12], &l, 4);
+        std::memcpy(&nodes[(size_t)node * 16 + 13], &r, 4);
+        return node;
+    }
+};
+
+// fills d.bvh_* ; returns the node array to upload
+std::vector<float> build_bvh(DevScene &d, int n_prims, const int32_t *prim_kind, const double *prim_geom, const double *cam, double t_lo, double t_hi) {
+    BvhBuilder B;
+    std::vector<BvhItem> all;
+    double obound = 0.0;
+    for (int k = 0; k < 3; ++k) obound = std::max(obound, std::fabs(cam[k]));
+    for (int i = 0; i < n_prims; ++i) {
+        const double *g = prim_geom + (size_t)i * RTMI_PRIM_STRIDE;
+        const double r = std::fabs(g[3]);
+        BvhItem it; it.idx = i;
+        bool ok = true;
+        if (prim_kind[i] == RTMI_PRIM_MOVING) {
+            const double f0 = (t_lo - g[7]) / (g[8] - g[7]), f1 = (t_hi - g[7]) / (g[8] - g[7]);
+            ok = std::isfinite(f0) && std::isfinite(f1);
+            for (int k = 0; k < 3 && ok; ++k) {
+                const double a0 = g[k] * (1.0 - f0) + g[4 + k] * f0, a1 = g[k] * (1.0 - f1) + g[4 + k] * f1;
+                const double slack = 1e-9 * (std::fabs(a0) + std::fabs(a1) + r);
+                it.b.lo[k] = std::min(a0, a1) - r - slack; it.b.hi[k] = std::max(a0, a1) + r + slack; it.cen[k] = 0.5 * (a0 + a1);
+            }
+        } else {
+            for (int k = 0; k < 3; ++k) { const double slack = 1e-9 * (std::fabs(g[k]) + r); it.b.lo[k] = g[k] - r - slack; it.b.hi[k] = g[k] + r + slack; it.cen[k] = g[k]; }
+        }
+        for (int k = 0; k < 3 && ok; ++k) ok = std::isfinite(it.b.lo[k]) && std::isfinite(it.b.hi[k]) && std::fabs(it.b.lo[k]) < 1e15 && std::fabs(it.b.hi[k]) < 1e15;
+        if (!ok) { for (int k = 0; k < 3; ++k) { it.b.lo[k] = -1e15; it.b.hi[k] = 1e15; it.cen[k] = 0; } } // unbounded: goes to the big list below
+        for (int k = 0; k < 3; ++k) obound = std::max(obound, std::max(std::fabs(it.b.lo[k]), std::fabs(it.b.hi[k])));
+        all.push_back(it);
+    }
+    obound = std::min(obound, 1e15) * 1.001 + 1e-30;
+    d.n_big = 0;
+    for (const BvhItem &it : all) {
+        const double ext = std::max(it.b.hi[0] - it.b.lo[0], std::max(it.b.hi[1] - it.b.lo[1], it.b.hi[2] - it.b.lo[2]));
+        if (ext >= 0.25 * obound && d.n_big < 16) d.big_idx[d.n_big++] = it.idx; // ascending index order
+        else B.items.push_back(it);
+    }
+    B.delta = obound * (1.0 / 4194304.0); // 2^-22 * obound
+    d.bvh_obound = f_down(obound);
+    if (B.items.empty()) d.bvh_root = RTMI_BVH_EMPTY;
+    else if (B.items.size() == 1) { // a lone primitive: a node whose right child is an empty box
+        B.nodes.assign(16, 0.0f);
+        B.put_box(0, 0, B.items[0].b);
+        for (int k = 0; k < 3; ++k) { B.nodes[6 + (size_t)k] = INFINITY; B.nodes[9 + (size_t)k] = -INFINITY; }
+        const int l = ~B.items[0].idx, r = ~B.items[0].idx;
+        std::memcpy(&B.nodes[12], &l, 4); std::memcpy(&B.nodes[13], &r, 4);
+        d.bvh_root = 0;
+    } else {
+        int lg = 1;
+        while ((1u << lg) < B.items.size()) ++lg;
+        B.sah_depth = std::max(2, RTMI_BVH_STACK - 2 - lg); // SAH levels + median levels (<= lg) stay below the stack size
+        d.bvh_root = B.build(0, (int)B.items.size(), 0);
+        if (B.max_depth >= RTMI_BVH_STACK - 1) { // cannot happen by construction; never risk the traversal stack
+            d.bvh_root = RTMI_BVH_EMPTY; d.n_big = 0; d.bvh_obound = -1.0f; // obound < 0: every ray takes the exact flat scan
+            B.nodes.clear();
+        }
+    }
+    return B.nodes;
 }
 
 int check_render_args(rtmi_scene *s, int nx, int ny, int ns, int depth, int precision) {
@@ -658,7 +807,7 @@ RTMI_EXPORT int rtmi_set_option(rtmi_ctx *c, const char *name, int64_t value) {
     if (!std::strcmp(name, "timing")) { if (value) c->flags |= RTMI_FLAG_TIMING; else c->flags &= ~RTMI_FLAG_TIMING; return RTMI_OK; }
     if (!std::strcmp(name, "scan_variant")) { if (value < 0 || value > 3) return fail(RTMI_E_ARG, "scan_variant must be 0..3"); c->scan_variant = (int)value; return RTMI_OK; }
     if (!std::strcmp(name, "accel")) {
-        if (value == RTMI_ACCEL_FLAT) { c->accel = (int)value; return RTMI_OK; }
+        if (value == RTMI_ACCEL_FLAT || value == RTMI_ACCEL_BVH) { c->accel = (int)value; return RTMI_OK; }
         return fail(RTMI_E_UNSUPPORTED, "accel %lld is not available in this build", (long long)value);
     }
     return fail(RTMI_E_ARG, "unknown option '%s'", name);
@@ -805,6 +954,8 @@ RTMI_EXPORT int rtmi_scene_create(rtmi_ctx *c, int32_t n_prims, const int32_t *p
         cull20.insert(cull20.end(), rec, rec + 20);
     }
     d.n_all = n_prims; d.cull_t_lo = t_lo; d.cull_t_hi = t_hi;
+    const std::vector<float> bvh_nodes = build_bvh(d, n_prims, prim_kind, prim_geom, cam, t_lo, t_hi);
+    if (!rc) rc = upload(s, bvh_nodes, &d.bvh_nodes);
     if (!rc) rc = upload(s, cull20, &d.cull20);
     if (!rc) rc = upload(s, exact12, &d.exact12);
     if (!rc) rc = upload(s, stat4_d, &d.stat4_d);
@@ -968,7 +1119,8 @@ RTMI_EXPORT int rtmi_probe_hit(rtmi_scene *s, int32_t precision, int32_t n, cons
     int ppt, npt; size_t lds;
     if (precision == RTMI_F64) {
         lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
-        switch (c->scan_variant) {
+        switch (c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant) {
+        case SCAN_BVH: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_BVH>), dim3(grid), dim3(kBlock), std::max(lds, (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16), c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
         case SCAN_SGPR_CULL: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_SGPR_CULL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
         case SCAN_SGPR: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_SGPR>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
         case SCAN_LDS_PIPE: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_LDS_PIPE>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
@@ -976,7 +1128,8 @@ RTMI_EXPORT int rtmi_probe_hit(rtmi_scene *s, int32_t precision, int32_t n, cons
         }
     } else {
         lds_plan(c, s->dev.n_static, sizeof(float), &ppt, &npt, &lds);
-        switch (c->scan_variant) {
+        switch (c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant) {
+        case SCAN_BVH: hipLaunchKernelGGL((probe_hit_kernel<float, SCAN_BVH>), dim3(grid), dim3(kBlock), std::max(lds, (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16), c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
         case SCAN_SGPR_CULL: hipLaunchKernelGGL((probe_hit_kernel<float, SCAN_SGPR_CULL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
         case SCAN_SGPR: hipLaunchKernelGGL((probe_hit_kernel<float, SCAN_SGPR>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
         case SCAN_LDS_PIPE: hipLaunchKernelGGL((probe_hit_kernel<float, SCAN_LDS_PIPE>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
@@ -1005,7 +1158,8 @@ RTMI_EXPORT int rtmi_probe_paths(rtmi_scene *s, int32_t precision, int32_t n, co
     int ppt, npt; size_t lds;
     if (precision == RTMI_F64) {
         lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
-        switch (c->scan_variant) {
+        switch (c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant) {
+        case SCAN_BVH: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_BVH>), dim3(grid), dim3(kBlock), std::max(lds, (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16), c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
         case SCAN_SGPR_CULL: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_SGPR_CULL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
         case SCAN_SGPR: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_SGPR>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
         case SCAN_LDS_PIPE: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_LDS_PIPE>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
@@ -1013,7 +1167,8 @@ RTMI_EXPORT int rtmi_probe_paths(rtmi_scene *s, int32_t precision, int32_t n, co
         }
     } else {
         lds_plan(c, s->dev.n_static, sizeof(float), &ppt, &npt, &lds);
-        switch (c->scan_variant) {
+        switch (c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant) {
+        case SCAN_BVH: hipLaunchKernelGGL((probe_paths_kernel<float, SCAN_BVH>), dim3(grid), dim3(kBlock), std::max(lds, (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16), c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
         case SCAN_SGPR_CULL: hipLaunchKernelGGL((probe_paths_kernel<float, SCAN_SGPR_CULL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
         case SCAN_SGPR: hipLaunchKernelGGL((probe_paths_kernel<float, SCAN_SGPR>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
         case SCAN_LDS_PIPE: hipLaunchKernelGGL((probe_paths_kernel<float, SCAN_LDS_PIPE>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;

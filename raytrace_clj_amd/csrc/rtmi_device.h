@@ -29,6 +29,12 @@ struct DevScene {
                              // a MovingSphere is represented by a sphere bounding its sweep over [cull_t_lo, cull_t_hi]
     const double *exact12;   // [round_up(n_all,8)+8][12] c0.xyz r*r c1.xyz t0 t1 moving? 0 0 (padded with copies of the last)
     double cull_t_lo, cull_t_hi; // ray times the swept bounds are valid for (the camera's [t0, t1])
+    // RTMI_ACCEL_BVH (the reference's bvh-node descent, hitable.clj:97-123, rebuilt for the device):
+    const float *bvh_nodes;  // [n_nodes][16]: left box lo.xyz hi.xyz, right box lo.xyz hi.xyz, left, right (int bits), 0, 0
+    int bvh_root;            // child code: >= 0 node index, < 0 = ~(original primitive index), 0x7fffffff = empty
+    int n_big;               // primitives too large to bound usefully (sky dome, ground): always tested exactly
+    int big_idx[16];
+    float bvh_obound;        // rays starting outside [-obound, obound]^3 bypass the float traversal
     const int *stat_orig;    // [n_static] index in the caller's Hitlist
     const double *mov_geom;  // [n_moving][9]  c0.xyz radius c1.xyz t0 t1
     const int *mov_orig;
@@ -208,7 +214,7 @@ template <typename R> struct alignas(16) Prim4 { R cx, cy, cz, r2; };
 // b' = oc.d:  disc = 4*fl(fl(b'b') - fl(a c)) = 4 disc',  sqrt(disc) = 2 sqrt(disc'),  t = fl((-b' -+ sqrt(disc'))/a)
 // bit for bit.  The kernels evaluate the primed form (two multiplies fewer per test); scan variant 0 keeps the
 // literal form so the parity tests can compare the two on the device.
-enum { SCAN_LDS_LITERAL = 0, SCAN_LDS_PIPE = 1, SCAN_SGPR = 2, SCAN_SGPR_CULL = 3 };
+enum { SCAN_LDS_LITERAL = 0, SCAN_LDS_PIPE = 1, SCAN_SGPR = 2, SCAN_SGPR_CULL = 3, SCAN_BVH = 4 };
 
 template <typename R>
 __device__ inline void scan_static(const Prim4<R> *__restrict__ lds, int n, int idx_base, const Path<R> &P, R a, R tmin, R &best_t, int &best_i) {
@@ -429,6 +435,115 @@ __device__ inline void scan_all_cull(SceneRef sc, const Path<double> &P, double 
         cull_test_group(A, g, last, exact12, P, c, a, tmin, behind_ok, best_t, best_i);
         A = load_cull_group(cull20, (g >> 2) + 2);
         cull_test_group(B, g + 4, last, exact12, P, c, a, tmin, behind_ok, best_t, best_i);
+    }
+}
+
+// ---- RTMI_ACCEL_BVH: per-lane BVH traversal with conservative float boxes, exact FP64 leaves -------------------------
+// Closest hit is order independent: candidate(prim) = first root if > t-min else second root (hitable.clj:192-207 with the
+// running t-max of hitable.clj:20 only ever rejecting non-minimal candidates); ties -> lowest Hitlist index (first wins).
+#define RTMI_BVH_EMPTY 0x7fffffff
+#define RTMI_BVH_STACK 32
+
+__device__ inline void sphere_roots_any_order(double bq, double cq, double disc, double a, double tmin, bool behind_ok, double &best_t, int &best_i, int idx) {
+    if (behind_ok && bq > 0.0 && cq > 0.0) return;
+    const double sq = ::sqrt(disc);
+    double t = (-bq - sq) / a;
+    if (!(t > tmin)) t = (-bq + sq) / a;
+    if ((t > tmin) && ((t < best_t) || (t == best_t && idx < best_i))) { best_t = t; best_i = idx; }
+}
+
+// exact test of primitive `idx` (per-lane index: vector loads)
+__device__ inline void exact_prim_test_lane(const double *exact12, int idx, const Path<double> &P, double a, double tmin, bool behind_ok,
+                                            double &best_t, int &best_i) {
+    const double *g = exact12 + (size_t)idx * 12;
+    Prim4<double> s;
+    s.cx = g[0]; s.cy = g[1]; s.cz = g[2]; s.r2 = g[3];
+    if (g[9] != 0.0) {
+        const double t0 = g[7], t1 = g[8];
+        const double f = (P.time - t0) / (t1 - t0), omf = 1.0 - f;
+        s.cx = g[0] * omf + g[4] * f; s.cy = g[1] * omf + g[5] * f; s.cz = g[2] * omf + g[6] * f;
+    }
+    double bq, cq, disc;
+    sphere_test(s, P, a, bq, cq, disc);
+    if (disc >= 0.0) sphere_roots_any_order(bq, cq, disc, a, tmin, behind_ok, best_t, best_i, idx);
+}
+
+// Conservative slab test in float.  The box planes were rounded outward and inflated by 2^-22 * obound on the host, which
+// covers |fl32(o) - o| <= 2^-24 obound for every safe ray; the remaining error of (plane - o_f) * inv_f is relative
+// (<= 4u), so the entry distance is lowered and the exit distance raised by 8u before comparing.
+__device__ inline bool box_hit(const float lo0, const float lo1, const float lo2, const float hi0, const float hi1, const float hi2,
+                               const float ox, const float oy, const float oz, const float ix, const float iy, const float iz,
+                               const float tmin_lo, const float best_hi, float &tnear) {
+    const float ax = (lo0 - ox) * ix, bx = (hi0 - ox) * ix;
+    const float ay = (lo1 - oy) * iy, by = (hi1 - oy) * iy;
+    const float az = (lo2 - oz) * iz, bz = (hi2 - oz) * iz;
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float ku = 8.0f * 5.9604645e-08f;
+    tn = tn - ku * fabsf(tn);
+    tf = tf + ku * fabsf(tf);
+    tnear = tn;
+    return (tn <= tf) && (tf >= tmin_lo) && (tn <= best_hi);
+}
+
+__device__ inline float float_up(double x) { // smallest float >= x (x finite, |x| < FLT_MAX)
+    float f = (float)x;
+    if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + (f >= 0.0f ? 1u : (unsigned)-1));
+    return f;
+}
+
+// stack: LDS, one column per thread (stack[level * blockDim.x + tid]: conflict-free)
+__device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, double &best_t, int &best_i) {
+    const bool behind_ok = tmin >= 0.0;
+    const double *exact12 = sc.exact12;
+    // rays the float traversal cannot bound take the exact flat scan (all primitives, original order) instead
+    const float ox = (float)P.ox, oy = (float)P.oy, oz = (float)P.oz;
+    const float dx = (float)P.dx, dy = (float)P.dy, dz = (float)P.dz;
+    const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+    const float ob = sc.bvh_obound;
+    const bool safe = (fabsf(ox) <= ob) && (fabsf(oy) <= ob) && (fabsf(oz) <= ob) && (dmax < 1e15f) && (dmax > 1e-15f) &&
+                      (fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= 1e-12f * dmax) && (a > 1e-30) && (a < 1e30) &&
+                      (P.time >= sc.cull_t_lo) && (P.time <= sc.cull_t_hi) && (tmin > -1e30) && (tmin < 1e30);
+    if (!safe) {
+        scan_all_cull(sc, P, a, tmin, best_t, best_i);
+        return;
+    }
+    // 1. the big primitives (sky dome, ground, ...): exact test, ascending Hitlist index
+    for (int k = 0; k < sc.n_big; ++k) exact_prim_test(exact12, sc.big_idx[k], sc.big_idx[k], P, a, tmin, behind_ok, best_t, best_i);
+    // 2. per-lane traversal
+    int node = sc.bvh_root;
+    if (node == RTMI_BVH_EMPTY) return;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float tmin_lo = -float_up(-tmin);
+    const int tid = threadIdx.x, stride = blockDim.x;
+    int sp = 0;
+    const float4 *nodes = reinterpret_cast<const float4 *>(sc.bvh_nodes);
+    for (;;) {
+        if (node >= 0) { // inner node: both child boxes come with it
+            const float4 n0 = nodes[(size_t)node * 4], n1 = nodes[(size_t)node * 4 + 1], n2 = nodes[(size_t)node * 4 + 2], n3 = nodes[(size_t)node * 4 + 3];
+            const float best_hi = best_t < 3.0e38 ? float_up(best_t) : 3.4028235e38f;
+            float tl, tr;
+            const bool hl = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ox, oy, oz, ix, iy, iz, tmin_lo, best_hi, tl);
+            const bool hr = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ox, oy, oz, ix, iy, iz, tmin_lo, best_hi, tr);
+            const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
+            if (hl && hr) {
+                const bool left_first = tl <= tr;
+                stack[sp * stride + tid] = left_first ? cr : cl;
+                ++sp;
+                node = left_first ? cl : cr;
+            } else if (hl) node = cl;
+            else if (hr) node = cr;
+            else {
+                if (sp == 0) break;
+                --sp;
+                node = stack[sp * stride + tid];
+            }
+        } else { // leaf: one primitive, exact FP64 test
+            exact_prim_test_lane(exact12, ~node, P, a, tmin, behind_ok, best_t, best_i);
+            if (sp == 0) break;
+            --sp;
+            node = stack[sp * stride + tid];
+        }
     }
 }
 

@@ -308,6 +308,51 @@ def test_scan_variants_are_bit_identical(oracle, cover11, cover11_moving):
         ctx.close()
 
 
+def test_bvh_accel_is_bit_identical(oracle, cover11, cover11_moving):
+    """RTMI_ACCEL_BVH (bvh-node descent, hitable.clj:97-123, rebuilt for the device) returns the closest hit of the flat
+    Hitlist scan bit for bit: probes (random + tangent + axis-parallel fallback rays), whole images, counters."""
+    scenes = [cover11, cover11_moving, r.scene.make_random_scene(64, 32, 50, True), r.scene.make_two_spheres(40, 20),
+              {"camera": cover11["camera"], "world": r.hitable.hitlist(items=[r.hitable.sphere(center=vec3(0, 0, -1), radius=0.5, material=MATERIAL)])},
+              {"camera": cover11["camera"], "world": r.hitable.hitlist(items=[])}]
+    for sc in scenes:
+        f = fl.flatten(sc)
+        ctx = core.Context(0)
+        ds = core.DeviceScene(f, ctx=ctx)
+        rays = random_rays(20000, 8)
+        if f.n_prims:
+            rays = np.concatenate([rays, tangent_rays(f, 60000, 9)])
+        axis = rays[:3000].copy(); axis[:, 4] = 0.0  # d.y = 0: not boundable in float -> exact flat-scan fallback
+        rays = np.concatenate([rays, axis])
+        ctx.set_option("accel", 0)
+        flat = ds.probe_hit(rays)
+        flat0 = ds.probe_hit(rays[:20000], 0.0, FLT_MAX)
+        img_flat = ds.render(96, 48, 6)
+        ctx.set_option("accel", 1)
+        bvh = ds.probe_hit(rays)
+        bvh0 = ds.probe_hit(rays[:20000], 0.0, FLT_MAX)
+        img_bvh = ds.render(96, 48, 6)
+        assert np.array_equal(flat, bvh) and np.array_equal(flat0, bvh0)
+        for a, b in zip(img_flat, img_bvh):
+            assert np.array_equal(a, b)
+        if f.n_prims:
+            assert np.array_equal(bvh[::11, :9], oracle.probe_hit(f, rays[::11])[:, :9])
+        ds.close()
+        ctx.close()
+
+
+def test_bvh_full_size_image_identical():
+    nx, ny, ns = 800, 400, 16
+    sc = r.scene.make_random_scene(nx, ny, 11, True)
+    ctx = core.Context(0)
+    ds = core.DeviceScene(sc, ctx=ctx)
+    flat = ds.render(nx, ny, ns)
+    ctx.set_option("accel", 1)
+    bvh = ds.render(nx, ny, ns)
+    ds.close(); ctx.close()
+    for a, b in zip(flat, bvh):
+        assert np.array_equal(a, b)
+
+
 def test_cull_handles_degenerate_rays():
     """rays the FP32 image cannot represent (huge / tiny / zero / NaN) must fall through to the exact test"""
     s = r.hitable.sphere(center=vec3(0, 0, 0), radius=1.0, material=MATERIAL)
