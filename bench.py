@@ -64,7 +64,8 @@ def main():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--accel", default="flat", choices=["flat", "bvh"], help="flat = Hitlist scan (hitable.clj:15-26); bvh = bvh-node descent (hitable.clj:97-123)")
+    ap.add_argument("--accel", default="bvh", choices=["flat", "bvh"], help="bvh = bvh-node descent (hitable.clj:97-123, what every reference scene builds); flat = Hitlist scan (hitable.clj:15-26)")
+    ap.add_argument("--single", action="store_true", help="do not also time the other acceleration structure")
     ap.add_argument("--scan-variant", type=int, default=-1, help="0 LDS literal, 1 LDS pipelined, 2 SGPR (default: library default)")
     args = ap.parse_args()
 
@@ -95,10 +96,11 @@ def main():
         ctx.set_option("blocks_per_cu", args.blocks_per_cu)
     if args.scan_variant >= 0:
         ctx.set_option("scan_variant", args.scan_variant)
-    if args.accel == "bvh":
-        ctx.set_option("accel", 1)
     ds = r.DeviceScene(flat, ctx=ctx)
     tr = rdist.TileRenderer(ds, nx, ny, rank, world)
+    n_prims = flat.n_prims
+    rec = 32 if args.precision == "f64" else 16
+    peak_t = FP64_PEAK_TFLOPS if args.precision == "f64" else FP32_PEAK_TFLOPS
 
     def barrier():
         torch.cuda.synchronize()
@@ -106,57 +108,80 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        tr.step(ns, precision=args.precision)
-    barrier()
-    ctx.last_trace_ms()  # reset the event window
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step(ns, precision=args.precision)
-    barrier()
-    dt = time.perf_counter() - t0
-    trace_ms, launches = ctx.last_trace_ms()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        seg = tr.counters[:1].clone()
-        dist.all_reduce(seg, op=dist.ReduceOp.SUM)
-        segments = int(seg.item())
-    else:
-        segments = int(tr.counters[0].item())
-
-    if rank == 0:
+    def measure(accel, steps, warmup):
+        """time `steps` steps of the path with the given acceleration structure; returns the result fields"""
+        ctx.set_option("accel", 1 if accel == "bvh" else 0)
+        for _ in range(warmup):
+            tr.step(ns, precision=args.precision)
+        barrier()
+        ctx.last_trace_ms()  # reset the event window
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step(ns, precision=args.precision)
+        barrier()
+        dt = time.perf_counter() - t0
+        trace_ms, launches = ctx.last_trace_ms()
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            seg = tr.counters[:1].clone()
+            dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+            segments = int(seg.item())
+        else:
+            segments = int(tr.counters[0].item())
         samples = nx * ny * ns
-        ms_per_step = dt / args.steps * 1e3
-        value = samples / (dt / args.steps) / 1e6
-        # roofline of the dominant kernel (trace_kernel) on rank 0: SURVEY.md 8(d) algorithmic figures per launch
-        rec = 32 if args.precision == "f64" else 16
-        seg_local = int(tr.counters[0].item())
-        n_prims = flat.n_prims
-        launches_per_step = max(1, launches // max(1, args.steps))
+        # roofline of the dominant kernel (trace_kernel) on this rank: SURVEY.md 8(d) algorithmic figures per launch
+        seg_local, pix_local = int(tr.counters[0].item()), int(tr.counters[1].item())
+        launches_per_step = max(1, launches // max(1, steps))
         launch_s = trace_ms / 1e3 / max(1, launches)
-        pix_local = int(tr.counters[1].item())
         bytes_alg = (seg_local * n_prims * rec / 256.0 + pix_local * 12.0) / launches_per_step
         flops_alg = seg_local * (n_prims * 20.0 + 120.0) / launches_per_step
         achieved = bytes_alg / launch_s / 1e9
-        peak_t = FP64_PEAK_TFLOPS if args.precision == "f64" else FP32_PEAK_TFLOPS
+        traffic = None
+        try:
+            t_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            e = t_all.get("%s/%s/%s" % (args.config, accel, args.precision))
+            if e and world == 1:
+                traffic = int((e["fetch_size_kb"] + e["write_size_kb"]) * 1024)
+        except (OSError, ValueError, KeyError):
+            pass
+        return {
+            "value": round(samples / (dt / steps) / 1e6, 3), "ms_per_step": round(dt / steps * 1e3, 4), "segments": segments,
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": traffic, "kernel": "trace_kernel<%s,%s>" % (args.precision, "BVH" if accel == "bvh" else "flat scan + FP32 cull"),
+                "launch_ms": round(launch_s * 1e3, 4), "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": round(bytes_alg),
+                "note": "algorithmic bytes = S*N*REC/256 + 12*pixels (SURVEY.md 8d: what the reference's Hitlist scan must touch with a "
+                        "256-ray LDS tile); the scene is on-chip (scalar cache / L2), so HBM is not what binds this path; traffic = "
+                        "rocprofv3 FETCH_SIZE+WRITE_SIZE of this kernel from profiles/ (the write is the 24 B/sample buffer)",
+                "valu": {"achieved": round(flops_alg / launch_s / 1e12, 3), "peak": peak_t, "unit": "TFLOP/s",
+                         "frac": round(flops_alg / launch_s / 1e12 / peak_t, 5),
+                         "note": "reference-equivalent flops S*(20N+120) per SURVEY.md 8d over the FP64 vector peak; the FP32 cull / "
+                                 "BVH skip most of that work, so this can exceed 1 -- it measures work avoided, not ALU utilisation"}}}
+
+    main_accel = args.accel
+    res = measure(main_accel, args.steps, args.warmup)
+    other = None
+    if world == 1 and not args.single:
+        other_accel = "flat" if main_accel == "bvh" else "bvh"
+        other = measure(other_accel, max(2, min(args.steps, 5)), 1)
+
+    if rank == 0:
+        samples = nx * ny * ns
         out = {
-            "metric": "Msamples/sec (nx*ny*ns)", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "metric": "Msamples/sec (nx*ny*ns)", "value": res["value"], "unit": "Msamples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "%s: %dx%dx%dspp Shirley cover scene n=%d (%d spheres%s), depth 50, thin-lens camera, "
                                    "seeded counter RNG; accel=%s; tiles dealt round-robin to %d GPU(s)" % (
-                                       args.config, nx, ny, ns, n, n_prims, ", moving" if moving else "", args.accel, world),
-                       "nx": nx, "ny": ny, "ns": ns, "spheres": n_prims, "depth": 50, "segments_per_sample": round(segments / samples, 4)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "trace_kernel", "launch_ms": round(launch_s * 1e3, 4), "launches_per_step": launches_per_step,
-                         "algorithmic_bytes_per_launch": round(bytes_alg),
-                         "valu": {"achieved": round(flops_alg / launch_s / 1e12, 3), "peak": peak_t, "unit": "TFLOP/s",
-                                  "frac": round(flops_alg / launch_s / 1e12 / peak_t, 5),
-                                  "note": "the sphere scan is VALU-bound, not HBM-bound (SURVEY.md 8d); flops = S*(20N+120)"}},
+                                       args.config, nx, ny, ns, n, n_prims, ", moving" if moving else "", main_accel, world),
+                       "nx": nx, "ny": ny, "ns": ns, "spheres": n_prims, "depth": 50, "accel": main_accel,
+                       "segments_per_sample": round(res["segments"] / samples, 4)},
+            "roofline": res["roofline"],
         }
+        if other is not None:
+            out["other_accel"] = {"accel": other_accel, "value": other["value"], "ms_per_step": other["ms_per_step"], "roofline": other["roofline"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat, nx, ny, ns)
         print(json.dumps(out), flush=True)

@@ -139,8 +139,7 @@ __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per
 
 // core.clj:43-51: jittered (u, v) for sample s of pixel (i, j), then the camera ray.
 template <typename R> __device__ inline void start_sample(SceneRef sc, const TraceParams &tp, int i, int j, int s, Path<R> &P) {
-    P.key = sample_key(tp.seed, (u64)j * (u64)tp.nx + (u64)i, (u64)s);
-    P.ctr = 0;
+    seed_stream(P, sample_key(tp.seed, (u64)j * (u64)tp.nx + (u64)i, (u64)s), 0u);
     const R u = ((R)(float)i + next_uniform(P)) / (R)tp.nx;
     const R v = ((R)(float)j + next_uniform(P)) / (R)tp.ny;
     get_ray<R>(sc, u, v, P);
@@ -170,7 +169,7 @@ __global__ void __launch_bounds__(kBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr 
     Path<R> P;
     P.ox = P.oy = P.oz = P.dx = P.dy = P.dz = P.time = R(0);
     P.ar = P.ag = P.ab = P.cr = P.cg = P.cb = R(0);
-    P.key = 0; P.ctr = 0; P.depth = 0;
+    seed_stream(P, 0ull, 0u); P.depth = 0;
     bool alive = false;
     bool exhausted = (total_m == 0);
     size_t out_idx = 0;
@@ -287,7 +286,7 @@ __global__ void __launch_bounds__(kBlock) assemble_kernel(const double *__restri
 // ---- probe kernels (one protocol call per thread; same device functions as trace_kernel) -------------
 template <typename R> __device__ inline void load_ray(const double *q, Path<R> &P) {
     P.ox = (R)q[0]; P.oy = (R)q[1]; P.oz = (R)q[2]; P.dx = (R)q[3]; P.dy = (R)q[4]; P.dz = (R)q[5]; P.time = (R)q[6];
-    P.ar = P.ag = P.ab = R(1); P.cr = P.cg = P.cb = R(0); P.key = 0; P.ctr = 0; P.depth = 0;
+    P.ar = P.ag = P.ab = R(1); P.cr = P.cg = P.cb = R(0); seed_stream(P, 0ull, 0u); P.depth = 0;
 }
 
 template <typename R, int VARIANT>
@@ -321,7 +320,7 @@ __global__ void __launch_bounds__(kBlock) probe_paths_kernel(ScenePtr scp, int p
     bool alive = k < n;
     Path<R> P;
     load_ray<R>(rays + (size_t)(alive ? k : 0) * 7, P);
-    P.key = alive ? keys[k] : 0; P.ctr = (unsigned)ctr0; P.depth = depth;
+    seed_stream(P, alive ? keys[k] : 0ull, (unsigned)ctr0); P.depth = depth;
     SegLog lg = {log ? log + (size_t)(alive ? k : 0) * max_seg * RTMI_SEG_REC : nullptr, max_seg, 0};
     u64 nseg = 0;
     const R tmin = R(0.001), tmax = Real<R>::tmax();
@@ -345,7 +344,7 @@ template <typename R> __global__ void probe_camera_kernel(ScenePtr scp, int n, c
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     Path<R> P;
-    P.key = keys[k]; P.ctr = 0; P.depth = 0;
+    seed_stream(P, keys[k], 0u); P.depth = 0;
     get_ray<R>(sc, (R)uv[2 * k], (R)uv[2 * k + 1], P);
     double *o = out + (size_t)k * 8;
     o[0] = P.ox; o[1] = P.oy; o[2] = P.oz; o[3] = P.dx; o[4] = P.dy; o[5] = P.dz; o[6] = P.time; o[7] = (double)P.ctr;
@@ -369,7 +368,7 @@ __global__ void probe_scatter_kernel(ScenePtr scp, int mat, int n, const double 
     if (k >= n) return;
     Path<R> P;
     load_ray<R>(rays + (size_t)k * 7, P);
-    P.key = keys[k]; P.ctr = 0; P.depth = 1;
+    seed_stream(P, keys[k], 0u); P.depth = 1;
     const double *hq = hits + (size_t)k * 8;
     HitRec<R> h;
     h.t = R(0); h.px = (R)hq[0]; h.py = (R)hq[1]; h.pz = (R)hq[2]; h.nx = (R)hq[3]; h.ny = (R)hq[4]; h.nz = (R)hq[5];

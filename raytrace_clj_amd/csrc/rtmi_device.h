@@ -97,11 +97,17 @@ template <typename R> struct Path {
     R ar, ag, ab;                   // atten
     R cr, cg, cb;                   // accum
     u64 key;
-    unsigned ctr;
+    u64 rs;       // running stream state = key + GOLD * ctr  (bits(key, d) = mix64(key + GOLD*(d+1)): one add per draw)
+    unsigned ctr; // draws consumed (reported by the probes)
     int depth;
 };
+template <typename R> __device__ inline void seed_stream(Path<R> &P, u64 key, unsigned ctr0) { P.key = key; P.ctr = ctr0; P.rs = key + RTMI_GOLD * (u64)ctr0; }
 
-template <typename R> __device__ inline R next_uniform(Path<R> &P) { return Real<R>::uniform(draw_bits(P.key, P.ctr++)); }
+template <typename R> __device__ inline R next_uniform(Path<R> &P) {
+    P.rs += RTMI_GOLD;
+    P.ctr++;
+    return Real<R>::uniform(mix64(P.rs));
+}
 
 template <typename R> __device__ inline R dot3(R ax, R ay, R az, R bx, R by, R bz) { return (ax * bx + ay * by) + az * bz; }
 
@@ -468,20 +474,22 @@ __device__ inline void exact_prim_test_lane(const double *exact12, int idx, cons
     if (disc >= 0.0) sphere_roots_any_order(bq, cq, disc, a, tmin, behind_ok, best_t, best_i, idx);
 }
 
-// Conservative slab test in float.  The box planes were rounded outward and inflated by 2^-22 * obound on the host, which
-// covers |fl32(o) - o| <= 2^-24 obound for every safe ray; the remaining error of (plane - o_f) * inv_f is relative
-// (<= 4u), so the entry distance is lowered and the exit distance raised by 8u before comparing.
+// Conservative slab test in float, FMA form: t = plane * inv_d + (-o * inv_d).  Error budget: the rounding of
+// c = fl(-o_f * inv) and of the fma are each equivalent to moving the plane by <= 2^-24 |o| (plus a relative 2u on t), and
+// |fl32(o) - o| <= 2^-24 |o|; the box planes were rounded outward and inflated by 2^-22 * obound >= 4 * 2^-24 |o| on the
+// host, which covers all three for every safe ray (|o| <= obound).  The remaining relative error (<= 4u with the rounding
+// of inv) is absorbed by lowering the entry distance and raising the exit distance by 8u before comparing.
 __device__ inline bool box_hit(const float lo0, const float lo1, const float lo2, const float hi0, const float hi1, const float hi2,
-                               const float ox, const float oy, const float oz, const float ix, const float iy, const float iz,
+                               const float cx, const float cy, const float cz, const float ix, const float iy, const float iz,
                                const float tmin_lo, const float best_hi, float &tnear) {
-    const float ax = (lo0 - ox) * ix, bx = (hi0 - ox) * ix;
-    const float ay = (lo1 - oy) * iy, by = (hi1 - oy) * iy;
-    const float az = (lo2 - oz) * iz, bz = (hi2 - oz) * iz;
+    const float ax = fmaf(lo0, ix, cx), bx = fmaf(hi0, ix, cx);
+    const float ay = fmaf(lo1, iy, cy), by = fmaf(hi1, iy, cy);
+    const float az = fmaf(lo2, iz, cz), bz = fmaf(hi2, iz, cz);
     float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     const float ku = 8.0f * 5.9604645e-08f;
-    tn = tn - ku * fabsf(tn);
-    tf = tf + ku * fabsf(tf);
+    tn = fmaf(-ku, fabsf(tn), tn);
+    tf = fmaf(ku, fabsf(tf), tf);
     tnear = tn;
     return (tn <= tf) && (tf >= tmin_lo) && (tn <= best_hi);
 }
@@ -510,21 +518,23 @@ __device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<double> &P, 
     }
     // 1. the big primitives (sky dome, ground, ...): exact test, ascending Hitlist index
     for (int k = 0; k < sc.n_big; ++k) exact_prim_test(exact12, sc.big_idx[k], sc.big_idx[k], P, a, tmin, behind_ok, best_t, best_i);
-    // 2. per-lane traversal
+    // 2. per-lane traversal, "while-while": every lane descends until it holds a leaf (or is done); then all lanes
+    //    holding a leaf run the exact FP64 test together -- the expensive FP64 code is not interleaved with box tests
     int node = sc.bvh_root;
     if (node == RTMI_BVH_EMPTY) return;
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float cx = -ox * ix, cy = -oy * iy, cz = -oz * iz;
     const float tmin_lo = -float_up(-tmin);
     const int tid = threadIdx.x, stride = blockDim.x;
     int sp = 0;
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.bvh_nodes);
-    for (;;) {
-        if (node >= 0) { // inner node: both child boxes come with it
+    float best_hi = best_t < 3.0e38 ? float_up(best_t) : 3.4028235e38f;
+    while (node != RTMI_BVH_EMPTY) {
+        while (node >= 0 && node != RTMI_BVH_EMPTY) { // inner node: both child boxes come with it (one 64-byte record)
             const float4 n0 = nodes[(size_t)node * 4], n1 = nodes[(size_t)node * 4 + 1], n2 = nodes[(size_t)node * 4 + 2], n3 = nodes[(size_t)node * 4 + 3];
-            const float best_hi = best_t < 3.0e38 ? float_up(best_t) : 3.4028235e38f;
             float tl, tr;
-            const bool hl = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ox, oy, oz, ix, iy, iz, tmin_lo, best_hi, tl);
-            const bool hr = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ox, oy, oz, ix, iy, iz, tmin_lo, best_hi, tr);
+            const bool hl = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, cx, cy, cz, ix, iy, iz, tmin_lo, best_hi, tl);
+            const bool hr = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, cx, cy, cz, ix, iy, iz, tmin_lo, best_hi, tr);
             const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
             if (hl && hr) {
                 const bool left_first = tl <= tr;
@@ -533,16 +543,14 @@ __device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<double> &P, 
                 node = left_first ? cl : cr;
             } else if (hl) node = cl;
             else if (hr) node = cr;
-            else {
-                if (sp == 0) break;
-                --sp;
-                node = stack[sp * stride + tid];
-            }
-        } else { // leaf: one primitive, exact FP64 test
+            else if (sp > 0) { --sp; node = stack[sp * stride + tid]; }
+            else node = RTMI_BVH_EMPTY;
+        }
+        if (node != RTMI_BVH_EMPTY) { // leaf: one primitive, exact FP64 test
             exact_prim_test_lane(exact12, ~node, P, a, tmin, behind_ok, best_t, best_i);
-            if (sp == 0) break;
-            --sp;
-            node = stack[sp * stride + tid];
+            best_hi = best_t < 3.0e38 ? float_up(best_t) : 3.4028235e38f;
+            if (sp > 0) { --sp; node = stack[sp * stride + tid]; }
+            else node = RTMI_BVH_EMPTY;
         }
     }
 }

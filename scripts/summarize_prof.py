@@ -25,3 +25,22 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
             print("  ", k)
             for c, v in sorted(cs.items()):
                 print("      %-28s mean/dispatch = %.6g  (n=%d)" % (c, sum(v) / len(v), len(v)))
+
+# traffic of the trace kernel for profiles/pmc_traffic.json: python scripts/summarize_prof.py <dir> --traffic KEY
+if len(sys.argv) > 3 and sys.argv[2] == "--traffic":
+    import json
+    vals = {}
+    for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "trace_kernel" in row["Kernel_Name"] and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    try:
+        allv = json.load(open(path))
+    except (OSError, ValueError):
+        allv = {}
+    allv[sys.argv[3]] = {"fetch_size_kb": sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]), "write_size_kb": sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]),
+                         "source": os.path.basename(out.rstrip("/")), "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per trace_kernel dispatch, KB; "
+                         "uncorrected: gfx950 halves FETCH_SIZE only for wide coalesced streams, this kernel's reads are 64-byte node / scalar loads"}
+    json.dump(allv, open(path, "w"), indent=1, sort_keys=True)
+    print("updated", path, sys.argv[3], allv[sys.argv[3]])
