@@ -82,10 +82,19 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    # RTMI_BENCH_REHEARSAL=1: several ranks share GPU 0 and the gather goes through gloo on the host -- only to rehearse the
+    # multi-rank control flow on a one-GPU box; never a measurement
+    rehearsal = os.environ.get("RTMI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            rdist.HOST_STAGED_GATHER = True
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     nx, ny, ns1, n, moving, mix = CONFIGS[args.config]
     ns = ns1 * world  # weak scaling: per-GPU work fixed
@@ -122,10 +131,11 @@ def main():
         dt = time.perf_counter() - t0
         trace_ms, launches = ctx.last_trace_ms()
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            coll_dev = "cpu" if rehearsal else "cuda"
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-            seg = tr.counters[:1].clone()
+            seg = tr.counters[:1].clone().to(coll_dev)
             dist.all_reduce(seg, op=dist.ReduceOp.SUM)
             segments = int(seg.item())
         else:

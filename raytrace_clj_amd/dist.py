@@ -10,6 +10,7 @@ from . import _ffi
 from .core import check
 
 TILE = _ffi.TILE
+HOST_STAGED_GATHER = False  # rehearsal only (gloo on a one-GPU box): stage the gather through host memory
 
 
 def n_tiles(nx, ny):
@@ -30,6 +31,14 @@ def gather_tiles(local_tiles, world, rank, dst=0, group=None):
     """local_tiles: [tiles_per_rank, 64, 3] float64 on this rank's device -> on dst: [world, tiles_per_rank, 64, 3]."""
     if world == 1:
         return local_tiles.unsqueeze(0)
+    if HOST_STAGED_GATHER:
+        host = local_tiles.cpu()
+        if rank == dst:
+            out = torch.empty((world,) + tuple(host.shape), dtype=host.dtype)
+            dist.gather(host, list(out.unbind(0)), dst=dst, group=group)
+            return out.to(local_tiles.device)
+        dist.gather(host, None, dst=dst, group=group)
+        return None
     if rank == dst:
         out = torch.empty((world,) + tuple(local_tiles.shape), dtype=local_tiles.dtype, device=local_tiles.device)
         dist.gather(local_tiles, list(out.unbind(0)), dst=dst, group=group)

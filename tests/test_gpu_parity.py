@@ -353,6 +353,80 @@ def test_bvh_full_size_image_identical():
         assert np.array_equal(a, b)
 
 
+def _random_scene(seed):
+    """a random world out of every in-scope record type, with awkward parameters"""
+    rng = np.random.default_rng(seed)
+    T, S, H = r.texture, r.shader, r.hitable
+    def colour():
+        return vec3(*rng.random(3))
+    def texture(depth=0):
+        k = rng.integers(0, 3 if depth < 2 else 2)
+        if k == 0:
+            return T.constant(color=colour())
+        if k == 1:
+            return T.uv_gradient(co=colour(), cu=colour(), cv=colour(), cuv=colour())
+        return T.checkerboard(tex0=texture(depth + 1), tex1=texture(depth + 1), scale=float(rng.choice([0.5, 3.0, 10.0, 37.0])))
+    def material():
+        k = rng.integers(0, 10)
+        if k < 4:
+            return S.lambertian(albedo=texture())
+        if k < 6:
+            return S.metal(albedo=texture(), fuzz=float(rng.choice([0.0, 0.3, 1.0, 10.0])))
+        if k < 8:
+            return S.dielectric(ri=float(rng.choice([1.5, 2.4, 1.0, 0.7])))
+        return S.diffuse_light(tex=texture())
+    t0, t1 = (0.0, 1.0) if seed % 2 else (0.25, 0.75)
+    items = [H.uv_sphere(center=vec3(0, 0, 0), radius=float(rng.choice([60.0, 1000.0])), material=S.diffuse_light(tex=texture()))]
+    for _ in range(int(rng.integers(1, 40))):
+        c = vec3(*rng.normal(0, 3, 3))
+        rad = float(rng.choice([0.05, 0.3, 1.0, 2.5]))
+        k = rng.integers(0, 4)
+        if k == 0:
+            items.append(H.uv_sphere(center=c, radius=rad, material=material()))
+        elif k == 1:
+            items.append(H.moving_sphere(center0=c, t0=float(rng.choice([0.0, -0.5, t0])), center1=c + vec3(*rng.normal(0, 1, 3)),
+                                         t1=float(rng.choice([1.0, 2.0, t1 + 0.1])), radius=rad, material=material()))
+        else:
+            items.append(H.sphere(center=c, radius=rad, material=material()))
+    if seed % 3 == 0:
+        items.append(H.sphere(center=vec3(0, -500.5, 0), radius=500.0, material=S.lambertian(albedo=texture())))
+    if seed % 2:
+        camera = r.camera.thin_lens_camera(lookfrom=vec3(*rng.normal(0, 6, 3)) + vec3(0, 2, 9), lookat=vec3(0, 0, 0), vup=vec3(0, 1, 0),
+                                           vfov=float(rng.choice([20, 50, 90])), aspect=1.5, aperture=float(rng.choice([0.0, 0.1, 1.0])),
+                                           focus_dist=8.0, t0=t0, t1=t1)
+    else:
+        camera = r.camera.pinhole_camera(lookfrom=vec3(*rng.normal(0, 6, 3)) + vec3(0, 2, 9), lookat=vec3(0, 0, 0), vup=vec3(0, 1, 0),
+                                         vfov=float(rng.choice([20, 50, 90])), aspect=1.5)
+    world = H.make_bvh(items, t0, t1) if seed % 4 else H.hitlist(items=items)
+    return {"camera": camera, "world": world}
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_match_oracle(oracle, seed):
+    sc = _random_scene(seed)
+    f = fl.flatten(sc)
+    nx, ny, ns = 48, 32, 6
+    exp_lin, exp_q, exp_cnt = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, nthreads=16)
+    rng = np.random.default_rng(seed)
+    n = 2000
+    keys = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+    cam = oracle.probe_camera(f, rng.random((n, 2)), keys)
+    ergb, enseg, elog, _ = oracle.probe_paths(f, cam[:, :7], keys, depth=50, ctr0=int(cam[:, 7].max()), max_seg=6)
+    ctx = core.Context(0)
+    ds = core.DeviceScene(f, ctx=ctx)
+    for accel in (0, 1):
+        ctx.set_option("accel", accel)
+        lin, q, cnt = ds.render(nx, ny, ns)
+        assert np.array_equal(cnt, exp_cnt), "accel %d" % accel
+        assert rms(lin, exp_lin) <= RMS_TOL and rms(lin, exp_lin) < 1e-12
+        assert np.abs(q.astype(int) - exp_q.astype(int)).max() <= 1
+        rgb, nseg, log, _ = ds.probe_paths(cam[:, :7], keys, depth=50, ctr0=int(cam[:, 7].max()), max_seg=6)
+        assert np.array_equal(nseg, enseg) and np.array_equal(log, elog)
+        assert np.allclose(rgb, ergb, atol=1e-11, rtol=0)
+    ds.close()
+    ctx.close()
+
+
 def test_cull_handles_degenerate_rays():
     """rays the FP32 image cannot represent (huge / tiny / zero / NaN) must fall through to the exact test"""
     s = r.hitable.sphere(center=vec3(0, 0, 0), radius=1.0, material=MATERIAL)
