@@ -626,7 +626,9 @@ inline float f_up(double x) { float f = (float)x; if ((double)f < x) f = std::ne
 struct BvhBuilder {
     std::vector<BvhItem> items;
     std::vector<float> nodes; // 16 floats per node
+    std::vector<char> moving; // by original primitive index
     double delta = 0.0;
+    int leaf_code(int idx) const { return ~(idx | (moving[(size_t)idx] ? 0x40000000 : 0)); }
     int sah_depth = 8, max_depth = 0;
     BvhBox bounds(int b, int e) const { BvhBox r = box_empty(); for (int i = b; i < e; ++i) box_grow(r, items[(size_t)i].b); return r; }
     void put_box(int node, int side, const BvhBox &b) {
@@ -635,7 +637,7 @@ struct BvhBuilder {
     }
     int build(int b, int e, int depth) { // returns the child code of the subtree over items [b, e)
         max_depth = std::max(max_depth, depth);
-        if (e - b == 1) return ~items[(size_t)b].idx;
+        if (e - b == 1) return leaf_code(items[(size_t)b].idx);
         const int node = (int)(nodes.size() / 16);
         nodes.resize(nodes.size() + 16, 0.0f);
         // split: binned SAH on the axis of largest centroid extent; median fallback (also beyond sah_depth, to bound the stack)
@@ -720,13 +722,15 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int32_t *prim_kind,
         else B.items.push_back(it);
     }
     B.delta = obound * (1.0 / 4194304.0); // 2^-22 * obound
+    B.moving.assign((size_t)std::max(n_prims, 1), 0);
+    for (int i = 0; i < n_prims; ++i) B.moving[(size_t)i] = prim_kind[i] == RTMI_PRIM_MOVING;
     d.bvh_obound = f_down(obound);
     if (B.items.empty()) d.bvh_root = RTMI_BVH_EMPTY;
     else if (B.items.size() == 1) { // a lone primitive: a node whose right child is an empty box
         B.nodes.assign(16, 0.0f);
         B.put_box(0, 0, B.items[0].b);
         for (int k = 0; k < 3; ++k) { B.nodes[6 + (size_t)k] = INFINITY; B.nodes[9 + (size_t)k] = -INFINITY; }
-        const int l = ~B.items[0].idx, r = ~B.items[0].idx;
+        const int l = B.leaf_code(B.items[0].idx), r = l;
         std::memcpy(&B.nodes[12], &l, 4); std::memcpy(&B.nodes[13], &r, 4);
         d.bvh_root = 0;
     } else {

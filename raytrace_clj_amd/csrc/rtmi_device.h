@@ -31,7 +31,7 @@ struct DevScene {
     double cull_t_lo, cull_t_hi; // ray times the swept bounds are valid for (the camera's [t0, t1])
     // RTMI_ACCEL_BVH (the reference's bvh-node descent, hitable.clj:97-123, rebuilt for the device):
     const float *bvh_nodes;  // [n_nodes][16]: left box lo.xyz hi.xyz, right box lo.xyz hi.xyz, left, right (int bits), 0, 0
-    int bvh_root;            // child code: >= 0 node index, < 0 = ~(original primitive index), 0x7fffffff = empty
+    int bvh_root;            // child code: >= 0 node index, < 0 = ~(original primitive index | moving << 30), 0x7fffffff = empty
     int n_big;               // primitives too large to bound usefully (sky dome, ground): always tested exactly
     int big_idx[16];
     float bvh_obound;        // rays starting outside [-obound, obound]^3 bypass the float traversal
@@ -458,16 +458,20 @@ __device__ inline void sphere_roots_any_order(double bq, double cq, double disc,
     if ((t > tmin) && ((t < best_t) || (t == best_t && idx < best_i))) { best_t = t; best_i = idx; }
 }
 
-// exact test of primitive `idx` (per-lane index: vector loads)
-__device__ inline void exact_prim_test_lane(const double *exact12, int idx, const Path<double> &P, double a, double tmin, bool behind_ok,
+// exact test of the primitive of leaf code `code` (per-lane: vector loads; a static sphere needs only its first 32 bytes)
+__device__ inline void exact_prim_test_lane(const double *exact12, int code, const Path<double> &P, double a, double tmin, bool behind_ok,
                                             double &best_t, int &best_i) {
-    const double *g = exact12 + (size_t)idx * 12;
+    const int bits = ~code;
+    const int idx = bits & 0x3fffffff;
+    const double2 *g = reinterpret_cast<const double2 *>(exact12 + (size_t)idx * 12);
+    const double2 g0 = g[0], g1 = g[1];
     Prim4<double> s;
-    s.cx = g[0]; s.cy = g[1]; s.cz = g[2]; s.r2 = g[3];
-    if (g[9] != 0.0) {
-        const double t0 = g[7], t1 = g[8];
+    s.cx = g0.x; s.cy = g0.y; s.cz = g1.x; s.r2 = g1.y;
+    if (bits & 0x40000000) { // MovingSphere
+        const double2 g2 = g[2], g3 = g[3], g4 = g[4];
+        const double t0 = g3.y, t1 = g4.x;
         const double f = (P.time - t0) / (t1 - t0), omf = 1.0 - f;
-        s.cx = g[0] * omf + g[4] * f; s.cy = g[1] * omf + g[5] * f; s.cz = g[2] * omf + g[6] * f;
+        s.cx = g0.x * omf + g2.x * f; s.cy = g0.y * omf + g2.y * f; s.cz = g1.x * omf + g3.x * f;
     }
     double bq, cq, disc;
     sphere_test(s, P, a, bq, cq, disc);
@@ -547,7 +551,7 @@ __device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<double> &P, 
             else node = RTMI_BVH_EMPTY;
         }
         if (node != RTMI_BVH_EMPTY) { // leaf: one primitive, exact FP64 test
-            exact_prim_test_lane(exact12, ~node, P, a, tmin, behind_ok, best_t, best_i);
+            exact_prim_test_lane(exact12, node, P, a, tmin, behind_ok, best_t, best_i);
             best_hi = best_t < 3.0e38 ? float_up(best_t) : 3.4028235e38f;
             if (sp > 0) { --sp; node = stack[sp * stride + tid]; }
             else node = RTMI_BVH_EMPTY;
