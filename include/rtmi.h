@@ -55,7 +55,10 @@ extern "C" {
 #define RTMI_E_NOMEM (-4)
 #define RTMI_E_STATE (-5)       /* handle used after destroy, wrong context, ... */
 
-enum { RTMI_PRIM_SPHERE = 0, RTMI_PRIM_UVSPHERE = 1, RTMI_PRIM_MOVING = 2 };
+enum { RTMI_PRIM_SPHERE = 0, RTMI_PRIM_UVSPHERE = 1, RTMI_PRIM_MOVING = 2,
+       /* section 8(f3), via rtmi_scene_create_ex: */
+       RTMI_PRIM_RECT_XY = 3, RTMI_PRIM_RECT_XZ = 4, RTMI_PRIM_RECT_YZ = 5, RTMI_PRIM_TRIANGLE = 6 };
+enum { RTMI_XFORM_TRANSLATE = 0, RTMI_XFORM_ROTATE_Y = 1 };
 enum { RTMI_MAT_LAMBERTIAN = 0, RTMI_MAT_METAL = 1, RTMI_MAT_DIELECTRIC = 2, RTMI_MAT_DIFFUSE_LIGHT = 3 };
 enum { RTMI_TEX_CONSTANT = 0, RTMI_TEX_UVGRADIENT = 1, RTMI_TEX_CHECKER = 2 };
 enum { RTMI_CAM_PINHOLE = 0, RTMI_CAM_THINLENS = 1 };
@@ -93,6 +96,23 @@ int rtmi_scene_create(rtmi_ctx *ctx,
                       int32_t n_mats, const int32_t *mat_kind, const int32_t *mat_tex, const double *mat_param,
                       int32_t n_tex, const int32_t *tex_kind, const double *tex_param, const int32_t *tex_child,
                       int32_t cam_kind, const double *cam, rtmi_scene **out_scene);
+/* The same plus the instancing records of hitable.clj:269-511, 548-581 (Cornell-box class scenes):
+ *   prim_kind[i] may also be RTMI_PRIM_RECT_XY/XZ/YZ (hitable.clj:269/301/333; prim_geom = a0, b0, a1, b1, k: the two in-plane
+ *   extents in the order of the record's fields, then the plane's coordinate) or RTMI_PRIM_TRIANGLE (hitable.clj:548;
+ *   prim_geom = v0.xyz, v1.xyz, v2.xyz);
+ *   prim_flip[i]      parity of the FlipNormals wrappers (hitable.clj:375) around primitive i;
+ *   prim_xform[i*2..] first index and count of primitive i's Translate / RotateY wrappers (hitable.clj:391, 410) in the
+ *                     xform table, OUTERMOST FIRST;  xform_kind[k] = RTMI_XFORM_*;
+ *   xform_param[k*3..] Translate: offset.xyz | RotateY: sin-theta, cos-theta, 0 (the record's fields, hitable.clj:410).
+ * Box (hitable.clj:491) flattens to its six rectangles.  ConstantMedium is not supported.  Scenes that use any of this are
+ * rendered by the FP64 kernels only (RTMI_F32 -> RTMI_E_UNSUPPORTED). */
+int rtmi_scene_create_ex(rtmi_ctx *ctx,
+                         int32_t n_prims, const int32_t *prim_kind, const double *prim_geom, const int32_t *prim_mat,
+                         int32_t n_mats, const int32_t *mat_kind, const int32_t *mat_tex, const double *mat_param,
+                         int32_t n_tex, const int32_t *tex_kind, const double *tex_param, const int32_t *tex_child,
+                         int32_t cam_kind, const double *cam,
+                         const int32_t *prim_flip, const int32_t *prim_xform,
+                         int32_t n_xforms, const int32_t *xform_kind, const double *xform_param, rtmi_scene **out_scene);
 int rtmi_scene_destroy(rtmi_scene *scene);
 
 /* ---- the hot path --------------------------------------------------------------------------- */

@@ -32,6 +32,8 @@ class _Scene(C.Structure):
         ("n_mats", C.c_int32), ("mat_kind", C.c_void_p), ("mat_tex", C.c_void_p), ("mat_param", C.c_void_p),
         ("n_tex", C.c_int32), ("tex_kind", C.c_void_p), ("tex_param", C.c_void_p), ("tex_child", C.c_void_p),
         ("cam_kind", C.c_int32), ("cam", C.c_void_p),
+        ("n_nodes", C.c_int32), ("node_kind", C.c_void_p), ("node_a", C.c_void_p), ("node_d", C.c_void_p),
+        ("node_prim", C.c_void_p), ("node_children", C.c_void_p), ("root", C.c_int32),
     ]
 
 
@@ -90,6 +92,15 @@ class Oracle:
         s.cam_kind = int(fs.cam_kind)
         for k, v in keep.items():
             setattr(s, k, v.ctypes.data)
+        tree = getattr(fs, "tree", None)  # optional nested world (oracle/tree.py)
+        if tree is not None:
+            tk = dict(node_kind=_i32(tree["kind"]), node_a=_i32(tree["a"]), node_d=_f64(tree["d"]), node_prim=_i32(tree["prim"]),
+                      node_children=_i32(tree["children"]))
+            s.n_nodes = len(tk["node_kind"])
+            s.root = int(tree["root"])
+            for k, v in tk.items():
+                setattr(s, k, v.ctypes.data)
+            keep.update(tk)
         s._keep = keep
         return s
 

@@ -87,7 +87,19 @@ typedef struct {
     const int32_t *tex_child; /* n_tex * 2 */
     int32_t cam_kind;
     const double *cam; /* 24: origin lleft horiz vert u v w aperture t0 t1 */
+    /* optional NESTED world (the reference's records as they are built, wrappers and bvh-nodes included); when
+     * n_nodes > 0 it replaces the flat primitive list above.  node_a[n][3] = child|left|first, right|count, material;
+     * node_d[n][12] = geometry; node_prim[n] = index the product's flattener gives this leaf (for logs), else -1. */
+    int32_t n_nodes;
+    const int32_t *node_kind;
+    const int32_t *node_a;
+    const double *node_d;
+    const int32_t *node_prim;
+    const int32_t *node_children; /* Hitlist items */
+    int32_t root;
 } rto_scene;
+enum { N_SPHERE = 0, N_UVSPHERE = 1, N_MOVING = 2, N_RECT_XY = 3, N_RECT_XZ = 4, N_RECT_YZ = 5, N_TRIANGLE = 6,
+       N_FLIP = 7, N_TRANSLATE = 8, N_ROTATE_Y = 9, N_HITLIST = 10, N_BOX = 11, N_BVH = 12 };
 
 typedef struct { real x, y, z; } v3;
 typedef struct { v3 o, d; real time; } ray_t;
@@ -234,8 +246,126 @@ static int sphere_hit(const rto_scene *sc, int32_t i, const ray_t *r, real tmin,
     return 0;
 }
 
+/* ---- nested world: every record of hitable.clj evaluated as the reference nests them ---- */
+RTO_API int rto_aabb_hit(const double *vmin, const double *vmax, const double *o, const double *d, double tmin, double tmax);
+static int sphere_like_hit(v3 center0, real radius, int kind, const double *g, const ray_t *r, real tmin, real tmax, hit_t *h) {
+    v3 center = center0;
+    if (kind == N_MOVING) { /* hitable.clj:219-222,227 */
+        real t0 = (real)g[7], t1 = (real)g[8];
+        center = vlerp(center0, ld3(g + 4), (r->time - t0) / (t1 - t0));
+    }
+    v3 oc = vsub(r->o, center);
+    real a = vdot(r->d, r->d);
+    real b = (real)2.0 * vdot(oc, r->d);
+    real c = vdot(oc, oc) - radius * radius;
+    real disc = b * b - ((real)4.0 * a) * c;
+    if (disc >= (real)0) {
+        real sq = R_SQRT(disc);
+        for (int root = 0; root < 2; ++root) {
+            real t = root == 0 ? (-b - sq) / ((real)2.0 * a) : (-b + sq) / ((real)2.0 * a);
+            if (t > tmin && t < tmax) {
+                h->t = t; h->p = point_at(r, t); h->n = vnormalise(vsub(h->p, center));
+                h->u = 0; h->v = 0;
+                if (kind == N_UVSPHERE) sphere_uv(h->n, &h->u, &h->v);
+                return 1;
+            }
+        }
+    }
+    return 0;
+}
+
+static int node_hit(const rto_scene *sc, int n, const ray_t *r, real tmin, real tmax, hit_t *h) {
+    const int kind = sc->node_kind[n];
+    const int32_t *a = sc->node_a + (size_t)n * 3;
+    const double *g = sc->node_d + (size_t)n * 12;
+    switch (kind) {
+    case N_SPHERE: case N_UVSPHERE: case N_MOVING:
+        if (!sphere_like_hit(ld3(g), (real)g[3], kind, g, r, tmin, tmax, h)) return 0;
+        h->prim = sc->node_prim[n]; h->mat = a[2];
+        return 1;
+    case N_RECT_XY: case N_RECT_XZ: case N_RECT_YZ: { /* hitable.clj:269-363: inclusive t range, inclusive extents */
+        const real a0 = (real)g[0], b0 = (real)g[1], a1 = (real)g[2], b1 = (real)g[3], k = (real)g[4];
+        const real o[3] = {r->o.x, r->o.y, r->o.z}, d[3] = {r->d.x, r->d.y, r->d.z};
+        const int ax = kind == N_RECT_XY ? 2 : (kind == N_RECT_XZ ? 1 : 0);          /* the plane's axis */
+        const int ua = kind == N_RECT_YZ ? 1 : 0, va = kind == N_RECT_XY ? 1 : 2;     /* the two in-plane axes */
+        const real t = (k - o[ax]) / d[ax];
+        if (!(t >= tmin && t <= tmax)) return 0;
+        const real x = o[ua] + t * d[ua], y = o[va] + t * d[va];
+        if (!(x >= a0 && x <= a1 && y >= b0 && y <= b1)) return 0;
+        h->t = t; h->p = point_at(r, t);
+        h->u = (x - a0) / (a1 - a0); h->v = (y - b0) / (b1 - b0);
+        h->n = V(ax == 0, ax == 1, ax == 2);
+        h->prim = sc->node_prim[n]; h->mat = a[2];
+        return 1;
+    }
+    case N_TRIANGLE: { /* hitable.clj:548-571 Moeller-Trumbore, one sided */
+        const v3 v0 = ld3(g), v1 = ld3(g + 3), v2 = ld3(g + 6);
+        const v3 v0v1 = vsub(v1, v0), v0v2 = vsub(v2, v0);
+        const v3 pvec = vcross(r->d, v0v2);
+        const real det = vdot(v0v1, pvec);
+        if (!(det > (real)0.00000001)) return 0;
+        const real inv_det = (real)1.0 / det;
+        const v3 tvec = vsub(r->o, v0);
+        const real u = vdot(tvec, pvec) * inv_det;
+        if (!(u > (real)0 && u <= (real)1)) return 0;
+        const v3 qvec = vcross(tvec, v0v1);
+        const real v = vdot(r->d, qvec) * inv_det;
+        if (!(v > (real)0 && u + v <= (real)1)) return 0;
+        const real t = vdot(v0v2, qvec) * inv_det;
+        if (!(t >= tmin && t <= tmax)) return 0;
+        h->t = t; h->p = point_at(r, t); h->u = u; h->v = v; h->n = vcross(v0v1, v0v2);
+        h->prim = sc->node_prim[n]; h->mat = a[2];
+        return 1;
+    }
+    case N_FLIP: /* hitable.clj:375-381 */
+        if (!node_hit(sc, a[0], r, tmin, tmax, h)) return 0;
+        h->n = vneg(h->n);
+        return 1;
+    case N_TRANSLATE: { /* hitable.clj:391-396 */
+        ray_t tr = *r;
+        tr.o = vsub(r->o, ld3(g));
+        if (!node_hit(sc, a[0], &tr, tmin, tmax, h)) return 0;
+        h->p = vadd(h->p, ld3(g));
+        return 1;
+    }
+    case N_ROTATE_Y: { /* hitable.clj:410-450 */
+        const real sn = (real)g[0], cs = (real)g[1];
+        ray_t rr;
+        rr.o = V(cs * r->o.x - sn * r->o.z, r->o.y, sn * r->o.x + cs * r->o.z);
+        rr.d = V(cs * r->d.x - sn * r->d.z, r->d.y, sn * r->d.x + cs * r->d.z);
+        rr.time = r->time;
+        if (!node_hit(sc, a[0], &rr, tmin, tmax, h)) return 0;
+        const v3 p = h->p, nn = h->n;
+        h->p = V(cs * p.x + sn * p.z, p.y, (-(sn * p.x)) + cs * p.z);
+        h->n = V(cs * nn.x + sn * nn.z, nn.y, (-(sn * nn.x)) + cs * nn.z);
+        return 1;
+    }
+    case N_BOX: /* hitable.clj:491-494: hit? of the six sides' Hitlist */
+        return node_hit(sc, a[0], r, tmin, tmax, h);
+    case N_HITLIST: { /* hitable.clj:15-26 */
+        int found = 0; real closest = tmax; hit_t tmp;
+        for (int k = 0; k < a[1]; ++k)
+            if (node_hit(sc, sc->node_children[a[0] + k], r, tmin, closest, &tmp)) { found = 1; closest = tmp.t; *h = tmp; }
+        return found;
+    }
+    case N_BVH: { /* hitable.clj:97-105: slab test, both children with the un-narrowed interval, ties -> right */
+        const double o[3] = {r->o.x, r->o.y, r->o.z}, d[3] = {r->d.x, r->d.y, r->d.z};
+        if (!rto_aabb_hit(g, g + 3, o, d, tmin, tmax)) return 0;
+        hit_t hl, hr;
+        const int fl = node_hit(sc, a[0], r, tmin, tmax, &hl), fr = node_hit(sc, a[1], r, tmin, tmax, &hr);
+        if (fl && fr) { *h = (hl.t < hr.t) ? hl : hr; return 1; }
+        if (fl) { *h = hl; return 1; }
+        if (fr) { *h = hr; return 1; }
+        return 0;
+    }
+    default:
+        return 0;
+    }
+}
+
 /* ---- hitable.clj:15-26 Hitlist: linear scan, each item tested with t-max = best so far ---- */
 static int hitlist_hit(const rto_scene *sc, const ray_t *r, real tmin, real tmax, hit_t *h) {
+    if (sc->n_nodes > 0) return node_hit(sc, sc->root, r, tmin, tmax, h);
     int found = 0;
     real closest = tmax;
     hit_t tmp;

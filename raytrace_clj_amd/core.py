@@ -83,10 +83,18 @@ class DeviceScene:
             (f.mat_kind, np.int32), (f.mat_tex, np.int32), (f.mat_param, np.float64),
             (f.tex_kind, np.int32), (f.tex_param, np.float64), (f.tex_child, np.int32), (f.cam, np.float64))]
         h = C.c_void_p()
-        check(_ffi.lib().rtmi_scene_create(
-            self.ctx.handle, len(keep[0]), ptr(keep[0]), ptr(keep[1]), ptr(keep[2]),
+        n = len(keep[0])
+        flip = np.ascontiguousarray(getattr(f, "prim_flip", np.zeros(n)), np.int32)
+        xform = np.ascontiguousarray(getattr(f, "prim_xform", np.zeros((n, 2))), np.int32)
+        xk = np.ascontiguousarray(getattr(f, "xform_kind", np.zeros(0)), np.int32)
+        xp = np.ascontiguousarray(getattr(f, "xform_param", np.zeros((0, 3))), np.float64)
+        if len(flip) != n or len(xform) != n:  # a FlatScene assembled by hand without the instancing arrays
+            flip, xform = np.zeros(n, np.int32), np.zeros((n, 2), np.int32)
+        check(_ffi.lib().rtmi_scene_create_ex(
+            self.ctx.handle, n, ptr(keep[0]), ptr(keep[1]), ptr(keep[2]),
             len(keep[3]), ptr(keep[3]), ptr(keep[4]), ptr(keep[5]),
-            len(keep[6]), ptr(keep[6]), ptr(keep[7]), ptr(keep[8]), int(f.cam_kind), ptr(keep[9]), C.byref(h)))
+            len(keep[6]), ptr(keep[6]), ptr(keep[7]), ptr(keep[8]), int(f.cam_kind), ptr(keep[9]),
+            ptr(flip), ptr(xform), len(xk), ptr(xk), ptr(xp), C.byref(h)))
         self.handle = h
 
     def close(self):
@@ -204,7 +212,7 @@ def hit(obj, r, t_min, t_max):
         ds.close()
     if o[0] == 0:
         return None
-    return {"t": o[2], "p": o[3:6].copy(), "uv": (o[9], o[10]), "normal": o[6:9].copy(), "material": leaves[int(o[1])].material}
+    return {"t": o[2], "p": o[3:6].copy(), "uv": (o[9], o[10]), "normal": o[6:9].copy(), "material": leaves[int(o[1])][0].material}
 
 
 class _Holder(hitm.Sphere):

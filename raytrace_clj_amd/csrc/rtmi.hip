@@ -91,9 +91,23 @@ __device__ inline void scan_bvh_dispatch(SceneRef sc, int *, const Path<float> &
 
 // hit? of the whole world for the lane's ray (closest hit, t in (t-min, t-max); core.clj:25 passes 0.001, Float/MAX_VALUE).
 // MULTI (LDS variants only): the static spheres do not fit one LDS tile; every thread of the workgroup must call this.
-template <typename R, bool MULTI, int VARIANT>
+// section 8(f3) scenes (FP64 only): BVH or culled flat scan over mixed primitive kinds with the any-order tie rule
+__device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, const Path<double> &P, bool active, double tmin, double tmax, double &best_t, int &best_i) {
+    best_t = tmax; best_i = -1;
+    if (!active) return;
+    const double a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
+    ExtHit H = {tmax, 0x7fffffff, -1, false};
+    if (bvh) scan_bvh_ext(sc, stack, P, a, tmin, H);
+    else scan_all_cull_ext(sc, P, a, tmin, H);
+    best_i = ext_winner(H);
+    if (best_i >= 0) best_t = H.t;
+}
+__device__ inline void intersect_ext(SceneRef, int *, bool, const Path<float> &, bool, float, float tmax, float &best_t, int &best_i) { best_t = tmax; best_i = -1; }
+
+template <typename R, bool MULTI, int VARIANT, bool EXT = false>
 __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, const Path<R> &P,
                                        bool active, R tmin, R tmax, R &best_t, int &best_i) {
+    if (EXT) { intersect_ext(sc, reinterpret_cast<int *>(lds), VARIANT == SCAN_BVH, P, active, tmin, tmax, best_t, best_i); return; }
     best_t = tmax;
     best_i = -1;
     const R a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
@@ -148,7 +162,7 @@ template <typename R> __device__ inline void start_sample(SceneRef sc, const Tra
     P.depth = tp.depth;
 }
 
-template <typename R, bool MULTI, int VARIANT>
+template <typename R, bool MULTI, int VARIANT, bool EXT = false>
 __global__ void __launch_bounds__(kBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
     SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -211,10 +225,10 @@ __global__ void __launch_bounds__(kBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr 
 
         // ---- one iteration of `color` for every live lane ---------------------------------------------
         R best_t; int best_i;
-        intersect_world<R, MULTI, VARIANT>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i);
+        intersect_world<R, MULTI, VARIANT, EXT>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i);
         if (alive) {
             ++nrays;
-            if (!shade_segment<R>(sc, P, best_t, best_i, nullptr)) {
+            if (!shade_segment<R, EXT>(sc, P, best_t, best_i, nullptr)) {
                 R *out = reinterpret_cast<R *>(tp.samples) + out_idx;
                 out[0] = P.cr; out[1] = P.cg; out[2] = P.cb;
                 alive = false;
@@ -289,7 +303,7 @@ template <typename R> __device__ inline void load_ray(const double *q, Path<R> &
     P.ar = P.ag = P.ab = R(1); P.cr = P.cg = P.cb = R(0); seed_stream(P, 0ull, 0u); P.depth = 0;
 }
 
-template <typename R, int VARIANT>
+template <typename R, int VARIANT, bool EXT = false>
 __global__ void __launch_bounds__(kBlock) probe_hit_kernel(ScenePtr scp, int prims_per_tile, int n_ptiles, int n, const double *rays, double tmin, double tmax, double *out) {
     SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -299,18 +313,18 @@ __global__ void __launch_bounds__(kBlock) probe_hit_kernel(ScenePtr scp, int pri
     Path<R> P;
     load_ray<R>(rays + (size_t)(active ? k : 0) * 7, P);
     R best_t; int best_i;
-    intersect_world<R, true, VARIANT>(sc, lds, prims_per_tile, n_ptiles, P, active, (R)tmin, (R)tmax, best_t, best_i);
+    intersect_world<R, true, VARIANT, EXT>(sc, lds, prims_per_tile, n_ptiles, P, active, (R)tmin, (R)tmax, best_t, best_i);
     if (!active) return;
     double *o = out + (size_t)k * 11;
     for (int c = 0; c < 11; ++c) o[c] = 0.0;
     if (best_i < 0) return;
     HitRec<R> h;
-    resolve_hit<R>(sc, P, best_t, best_i, h);
+    resolve_any<R, EXT>(sc, P, best_t, best_i, h);
     o[0] = 1.0; o[1] = h.orig; o[2] = h.t; o[3] = h.px; o[4] = h.py; o[5] = h.pz;
     o[6] = h.nx; o[7] = h.ny; o[8] = h.nz; o[9] = h.u; o[10] = h.v;
 }
 
-template <typename R, int VARIANT>
+template <typename R, int VARIANT, bool EXT = false>
 __global__ void __launch_bounds__(kBlock) probe_paths_kernel(ScenePtr scp, int prims_per_tile, int n_ptiles, int n, const double *rays, const u64 *keys, u64 ctr0,
                                                              int depth, double *out_rgb, u64 *out_nseg, double *log, int max_seg, int *out_nlog) {
     SceneRef sc = *scp;
@@ -326,10 +340,10 @@ __global__ void __launch_bounds__(kBlock) probe_paths_kernel(ScenePtr scp, int p
     const R tmin = R(0.001), tmax = Real<R>::tmax();
     while (__syncthreads_or(alive ? 1 : 0)) {
         R best_t; int best_i;
-        intersect_world<R, true, VARIANT>(sc, lds, prims_per_tile, n_ptiles, P, alive, tmin, tmax, best_t, best_i);
+        intersect_world<R, true, VARIANT, EXT>(sc, lds, prims_per_tile, n_ptiles, P, alive, tmin, tmax, best_t, best_i);
         if (alive) {
             ++nseg;
-            alive = shade_segment<R>(sc, P, best_t, best_i, log ? &lg : nullptr);
+            alive = shade_segment<R, EXT>(sc, P, best_t, best_i, log ? &lg : nullptr);
         }
     }
     if (k < n) {
@@ -572,14 +586,21 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         tp.nx = nx; tp.ny = ny; tp.depth = depth; tp.seed = seed; tp.tiles_x = tiles_x_of(nx);
         tp.n_local_tiles = n_local; tp.tile_ids = reinterpret_cast<const int *>(c->tile_ids.p);
         tp.s_begin = s_begin; tp.s_count = s_count; tp.samples = c->samples.p; tp.counters = cnt;
-        tp.prims_per_tile = c->scan_variant >= SCAN_SGPR ? 0 : ppt; tp.n_ptiles = nptiles;
+        tp.prims_per_tile = (c->scan_variant >= SCAN_SGPR || s->dev.has_ext) ? 0 : ppt; tp.n_ptiles = nptiles;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if ((c->flags & RTMI_FLAG_TIMING) && c->events_used < 8192) {
             rc = next_event_pair(c, &e0, &e1);
             if (rc) return rc;
             HIP_TRY(hipEventRecord(e0, st));
         }
-        switch (c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant) {
+        const int variant = c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant;
+        if (s->dev.has_ext) { // section 8(f3) scenes: FP64 kernels with the mixed-kind intersectors
+            if (variant == SCAN_BVH)
+                hipLaunchKernelGGL((trace_kernel<double, false, SCAN_BVH, true>), dim3(grid_trace), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, st, s->d_dev, tp);
+            else
+                hipLaunchKernelGGL((trace_kernel<double, false, SCAN_SGPR_CULL, true>), dim3(grid_trace), dim3(kBlock), 16, st, s->d_dev, tp);
+        } else
+        switch (variant) {
         case SCAN_BVH:
             hipLaunchKernelGGL((trace_kernel<R, false, SCAN_BVH>), dim3(grid_trace), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, st, s->d_dev, tp);
             break;
@@ -687,30 +708,64 @@ struct BvhBuilder {
     }
 };
 
-// fills d.bvh_* ; returns the node array to upload
-std::vector<float> build_bvh(DevScene &d, int n_prims, const int32_t *prim_kind, const double *prim_geom, const double *cam, double t_lo, double t_hi) {
+// World-space box of primitive i in double (with a little slack): the local box of the innermost record, then each
+// instance wrapper's outward map applied to its 8 corners, innermost wrapper first (RotateY: hitable.clj:441-443; Translate: 396).
+// MovingSpheres: the sweep over the shutter interval.  Returns false when the primitive cannot be bounded.
+bool prim_world_box(int kind, const double *g, const int32_t *xf_kind, const double *xf_param, int xf_first, int xf_count,
+                    double t_lo, double t_hi, BvhBox &out) {
+    BvhBox b;
+    if (kind <= RTMI_PRIM_MOVING) {
+        const double r = std::fabs(g[3]);
+        if (kind == RTMI_PRIM_MOVING) {
+            const double f0 = (t_lo - g[7]) / (g[8] - g[7]), f1 = (t_hi - g[7]) / (g[8] - g[7]);
+            if (!std::isfinite(f0) || !std::isfinite(f1)) return false;
+            for (int k = 0; k < 3; ++k) {
+                const double a0 = g[k] * (1.0 - f0) + g[4 + k] * f0, a1 = g[k] * (1.0 - f1) + g[4 + k] * f1;
+                b.lo[k] = std::min(a0, a1) - r; b.hi[k] = std::max(a0, a1) + r;
+            }
+        } else for (int k = 0; k < 3; ++k) { b.lo[k] = g[k] - r; b.hi[k] = g[k] + r; }
+    } else if (kind <= RTMI_PRIM_RECT_YZ) {
+        const int ax = kind == RTMI_PRIM_RECT_XY ? 2 : (kind == RTMI_PRIM_RECT_XZ ? 1 : 0);
+        const int ua = kind == RTMI_PRIM_RECT_YZ ? 1 : 0, va = kind == RTMI_PRIM_RECT_XY ? 1 : 2;
+        b.lo[ua] = std::min(g[0], g[2]); b.hi[ua] = std::max(g[0], g[2]);
+        b.lo[va] = std::min(g[1], g[3]); b.hi[va] = std::max(g[1], g[3]);
+        b.lo[ax] = g[4]; b.hi[ax] = g[4];
+    } else {
+        for (int k = 0; k < 3; ++k) { b.lo[k] = std::min(g[k], std::min(g[3 + k], g[6 + k])); b.hi[k] = std::max(g[k], std::max(g[3 + k], g[6 + k])); }
+    }
+    for (int q = xf_count - 1; q >= 0; --q) {
+        const double *p = xf_param + (size_t)(xf_first + q) * 3;
+        BvhBox nb = box_empty();
+        for (int c = 0; c < 8; ++c) {
+            double x = (c & 1) ? b.hi[0] : b.lo[0], y = (c & 2) ? b.hi[1] : b.lo[1], z = (c & 4) ? b.hi[2] : b.lo[2];
+            if (xf_kind[xf_first + q] == RTMI_XFORM_TRANSLATE) { x += p[0]; y += p[1]; z += p[2]; }
+            else { const double sn = p[0], cs = p[1]; const double rx = cs * x + sn * z, rz = -(sn * x) + cs * z; x = rx; z = rz; }
+            const double pt[3] = {x, y, z};
+            for (int k = 0; k < 3; ++k) { nb.lo[k] = std::min(nb.lo[k], pt[k]); nb.hi[k] = std::max(nb.hi[k], pt[k]); }
+        }
+        b = nb;
+    }
+    for (int k = 0; k < 3; ++k) {
+        if (!std::isfinite(b.lo[k]) || !std::isfinite(b.hi[k]) || std::fabs(b.lo[k]) > 1e15 || std::fabs(b.hi[k]) > 1e15) return false;
+        const double slack = 1e-9 * (std::fabs(b.lo[k]) + std::fabs(b.hi[k])) + 1e-12;
+        b.lo[k] -= slack; b.hi[k] += slack;
+    }
+    out = b;
+    return true;
+}
+
+// fills d.bvh_* ; returns the node array to upload.  wbox[i] / bounded[i]: prim_world_box of every primitive.
+std::vector<float> build_bvh(DevScene &d, int n_prims, const int32_t *prim_kind, const std::vector<BvhBox> &wbox, const std::vector<char> &bounded, const double *cam) {
     BvhBuilder B;
     std::vector<BvhItem> all;
     double obound = 0.0;
     for (int k = 0; k < 3; ++k) obound = std::max(obound, std::fabs(cam[k]));
     for (int i = 0; i < n_prims; ++i) {
-        const double *g = prim_geom + (size_t)i * RTMI_PRIM_STRIDE;
-        const double r = std::fabs(g[3]);
         BvhItem it; it.idx = i;
-        bool ok = true;
-        if (prim_kind[i] == RTMI_PRIM_MOVING) {
-            const double f0 = (t_lo - g[7]) / (g[8] - g[7]), f1 = (t_hi - g[7]) / (g[8] - g[7]);
-            ok = std::isfinite(f0) && std::isfinite(f1);
-            for (int k = 0; k < 3 && ok; ++k) {
-                const double a0 = g[k] * (1.0 - f0) + g[4 + k] * f0, a1 = g[k] * (1.0 - f1) + g[4 + k] * f1;
-                const double slack = 1e-9 * (std::fabs(a0) + std::fabs(a1) + r);
-                it.b.lo[k] = std::min(a0, a1) - r - slack; it.b.hi[k] = std::max(a0, a1) + r + slack; it.cen[k] = 0.5 * (a0 + a1);
-            }
-        } else {
-            for (int k = 0; k < 3; ++k) { const double slack = 1e-9 * (std::fabs(g[k]) + r); it.b.lo[k] = g[k] - r - slack; it.b.hi[k] = g[k] + r + slack; it.cen[k] = g[k]; }
-        }
-        for (int k = 0; k < 3 && ok; ++k) ok = std::isfinite(it.b.lo[k]) && std::isfinite(it.b.hi[k]) && std::fabs(it.b.lo[k]) < 1e15 && std::fabs(it.b.hi[k]) < 1e15;
-        if (!ok) { for (int k = 0; k < 3; ++k) { it.b.lo[k] = -1e15; it.b.hi[k] = 1e15; it.cen[k] = 0; } } // unbounded: goes to the big list below
+        if (bounded[(size_t)i]) {
+            it.b = wbox[(size_t)i];
+            for (int k = 0; k < 3; ++k) it.cen[k] = 0.5 * (it.b.lo[k] + it.b.hi[k]);
+        } else { for (int k = 0; k < 3; ++k) { it.b.lo[k] = -1e15; it.b.hi[k] = 1e15; it.cen[k] = 0; } } // unbounded: goes to the big list below
         for (int k = 0; k < 3; ++k) obound = std::max(obound, std::max(std::fabs(it.b.lo[k]), std::fabs(it.b.hi[k])));
         all.push_back(it);
     }
@@ -751,6 +806,7 @@ int check_render_args(rtmi_scene *s, int nx, int ny, int ns, int depth, int prec
     if (nx <= 0 || ny <= 0 || ns <= 0 || depth < 0) return fail(RTMI_E_ARG, "nx, ny, ns must be > 0 and depth >= 0 (got %d %d %d %d)", nx, ny, ns, depth);
     if ((long long)nx * ny > (1ll << 30)) return fail(RTMI_E_ARG, "frame too large");
     if (precision != RTMI_F64 && precision != RTMI_F32) return fail(RTMI_E_ARG, "precision must be RTMI_F64 or RTMI_F32");
+    if (precision == RTMI_F32 && s->dev.has_ext) return fail(RTMI_E_UNSUPPORTED, "rectangles / triangles / instances are rendered by the FP64 kernels only");
     return RTMI_OK;
 }
 
@@ -830,7 +886,19 @@ RTMI_EXPORT int rtmi_scene_create(rtmi_ctx *c, int32_t n_prims, const int32_t *p
                                   int32_t n_mats, const int32_t *mat_kind, const int32_t *mat_tex, const double *mat_param,
                                   int32_t n_tex, const int32_t *tex_kind, const double *tex_param, const int32_t *tex_child,
                                   int32_t cam_kind, const double *cam, rtmi_scene **out_scene) {
+    return rtmi_scene_create_ex(c, n_prims, prim_kind, prim_geom, prim_mat, n_mats, mat_kind, mat_tex, mat_param, n_tex, tex_kind, tex_param, tex_child,
+                                cam_kind, cam, nullptr, nullptr, 0, nullptr, nullptr, out_scene);
+}
+
+RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t *prim_kind, const double *prim_geom, const int32_t *prim_mat,
+                                     int32_t n_mats, const int32_t *mat_kind, const int32_t *mat_tex, const double *mat_param,
+                                     int32_t n_tex, const int32_t *tex_kind, const double *tex_param, const int32_t *tex_child,
+                                     int32_t cam_kind, const double *cam, const int32_t *prim_flip, const int32_t *prim_xform,
+                                     int32_t n_xforms, const int32_t *xform_kind, const double *xform_param, rtmi_scene **out_scene) {
     if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (n_xforms < 0 || (n_xforms > 0 && (!xform_kind || !xform_param || !prim_xform))) return fail(RTMI_E_ARG, "xform arrays are NULL");
+    for (int k = 0; k < n_xforms; ++k)
+        if (xform_kind[k] != RTMI_XFORM_TRANSLATE && xform_kind[k] != RTMI_XFORM_ROTATE_Y) return fail(RTMI_E_UNSUPPORTED, "xform %d: kind %d unsupported on GPU path", k, xform_kind[k]);
     if (!out_scene) return fail(RTMI_E_ARG, "out_scene is NULL");
     *out_scene = nullptr;
     if (n_prims < 0 || n_mats < 0 || n_tex < 0) return fail(RTMI_E_ARG, "negative count");
@@ -854,13 +922,17 @@ RTMI_EXPORT int rtmi_scene_create(rtmi_ctx *c, int32_t n_prims, const int32_t *p
     }
     std::vector<double> stat_geom, mov_geom, stat4_d;
     std::vector<float> stat4_f;
+    bool has_ext = false;
     std::vector<int> stat_orig, mov_orig, pk((size_t)n_prims), pm((size_t)n_prims);
     for (int i = 0; i < n_prims; ++i) {
         const int kind = prim_kind[i];
-        if (kind < RTMI_PRIM_SPHERE || kind > RTMI_PRIM_MOVING) return fail(RTMI_E_UNSUPPORTED, "primitive %d: kind %d unsupported on GPU path", i, kind);
+        if (kind < RTMI_PRIM_SPHERE || kind > RTMI_PRIM_TRIANGLE) return fail(RTMI_E_UNSUPPORTED, "primitive %d: kind %d unsupported on GPU path", i, kind);
         if (prim_mat[i] < 0 || prim_mat[i] >= n_mats) return fail(RTMI_E_ARG, "primitive %d: material index %d invalid", i, prim_mat[i]);
         pk[(size_t)i] = kind; pm[(size_t)i] = prim_mat[i];
         const double *g = prim_geom + (size_t)i * RTMI_PRIM_STRIDE;
+        const int xf_first = prim_xform ? prim_xform[2 * i] : 0, xf_count = prim_xform ? prim_xform[2 * i + 1] : 0;
+        if (xf_count < 0 || xf_first < 0 || xf_first + xf_count > n_xforms) return fail(RTMI_E_ARG, "primitive %d: xform range [%d, %d) invalid", i, xf_first, xf_first + xf_count);
+        if (kind > RTMI_PRIM_MOVING || xf_count > 0 || (prim_flip && prim_flip[i])) { has_ext = true; continue; }
         if (kind == RTMI_PRIM_MOVING) {
             mov_geom.insert(mov_geom.end(), g, g + RTMI_PRIM_STRIDE);
             mov_orig.push_back(i);
@@ -903,10 +975,49 @@ RTMI_EXPORT int rtmi_scene_create(rtmi_ctx *c, int32_t n_prims, const int32_t *p
     const double t_hi = cam_kind == RTMI_CAM_THINLENS ? std::max(cam[22], cam[23]) : 0.0;
     std::vector<double> exact12;
     std::vector<float> cull_c, cull_r2, cull_w; // per primitive: centre (3), r2, w
+    std::vector<BvhBox> wbox((size_t)n_prims);
+    std::vector<char> bounded((size_t)n_prims, 0);
+    std::vector<int> ext_info;
+    std::vector<double> ext_xf;
+    for (int k = 0; k < n_xforms; ++k) {
+        const double *p = xform_param + (size_t)k * 3;
+        const double rec[4] = {xform_kind[k] == RTMI_XFORM_TRANSLATE ? 0.0 : 1.0, p[0], p[1], p[2]};
+        ext_xf.insert(ext_xf.end(), rec, rec + 4);
+    }
     for (int i = 0; i < n_prims; ++i) {
         const double *g = prim_geom + (size_t)i * RTMI_PRIM_STRIDE;
-        const bool moving = prim_kind[i] == RTMI_PRIM_MOVING;
+        const int kind = prim_kind[i];
+        const int xf_first = prim_xform ? prim_xform[2 * i] : 0, xf_count = prim_xform ? prim_xform[2 * i + 1] : 0;
+        const int info[4] = {kind, prim_flip ? (prim_flip[i] & 1) : 0, xf_first, xf_count};
+        ext_info.insert(ext_info.end(), info, info + 4);
+        bounded[(size_t)i] = prim_world_box(kind, g, xform_kind, xform_param, xf_first, xf_count, t_lo, t_hi, wbox[(size_t)i]);
+        const bool moving = kind == RTMI_PRIM_MOVING;
         const volatile double r2d = g[3] * g[3];
+        if (kind > RTMI_PRIM_MOVING || xf_count > 0) { // f3 primitive or instanced sphere: cull by the sphere around its world box
+            if (kind > RTMI_PRIM_MOVING) exact12.insert(exact12.end(), {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], 0.0, 0.0, 0.0});
+            else exact12.insert(exact12.end(), {g[0], g[1], g[2], (double)r2d, g[4], g[5], g[6], g[7], g[8], moving ? 1.0 : 0.0, 0.0, 0.0});
+            float cf[3] = {0, 0, 0};
+            double r2b = 3.0e38, w = 3.0e38;
+            if (bounded[(size_t)i]) {
+                const BvhBox &b = wbox[(size_t)i];
+                double slack = 0.0, rb2 = 0.0, cn = 0.0;
+                for (int k = 0; k < 3; ++k) {
+                    const double cm = 0.5 * (b.lo[k] + b.hi[k]);
+                    cf[k] = (float)cm;
+                    slack += std::fabs(cm - (double)cf[k]);
+                    rb2 += 0.25 * (b.hi[k] - b.lo[k]) * (b.hi[k] - b.lo[k]);
+                    cn += std::fabs((double)cf[k]);
+                }
+                const double rb = (std::sqrt(rb2) + slack + 1e-4) * (1.0 + 1e-6); // 1e-4: the reference's own rect/triangle bbox padding scale
+                r2b = rb * rb * (1.0 + 1e-6);
+                w = (2.0 * (cn + slack) * (cn + slack) + r2b) * 1.0001;
+                if (!std::isfinite(w) || w > 1e37) { w = 3.0e38; r2b = 3.0e38; }
+            }
+            cull_c.insert(cull_c.end(), cf, cf + 3);
+            cull_r2.push_back((float)std::min(r2b * (1.0 + 1e-6), 3.0e38));
+            cull_w.push_back((float)std::min(w, 3.0e38));
+            continue;
+        }
         const double rec[12] = {g[0], g[1], g[2], (double)r2d, g[4], g[5], g[6], g[7], g[8], moving ? 1.0 : 0.0, 0.0, 0.0};
         exact12.insert(exact12.end(), rec, rec + 12);
         double cm[3] = {g[0], g[1], g[2]}, rb = std::fabs(g[3]);
@@ -957,8 +1068,11 @@ RTMI_EXPORT int rtmi_scene_create(rtmi_ctx *c, int32_t n_prims, const int32_t *p
         cull20.insert(cull20.end(), rec, rec + 20);
     }
     d.n_all = n_prims; d.cull_t_lo = t_lo; d.cull_t_hi = t_hi;
-    const std::vector<float> bvh_nodes = build_bvh(d, n_prims, prim_kind, prim_geom, cam, t_lo, t_hi);
+    const std::vector<float> bvh_nodes = build_bvh(d, n_prims, prim_kind, wbox, bounded, cam);
     if (!rc) rc = upload(s, bvh_nodes, &d.bvh_nodes);
+    d.has_ext = has_ext ? 1 : 0;
+    if (!rc) rc = upload(s, ext_info, &d.ext_info);
+    if (!rc) rc = upload(s, ext_xf, &d.ext_xf);
     if (!rc) rc = upload(s, cull20, &d.cull20);
     if (!rc) rc = upload(s, exact12, &d.exact12);
     if (!rc) rc = upload(s, stat4_d, &d.stat4_d);
@@ -1116,12 +1230,17 @@ struct Tmp { // scoped device temporaries for the (synchronous) probe entry poin
 RTMI_EXPORT int rtmi_probe_hit(rtmi_scene *s, int32_t precision, int32_t n, const double *rays, double t_min, double t_max, double *out) {
     PROBE_PROLOGUE(s)
     if (!rays || !out) return fail(RTMI_E_ARG, "NULL array");
+    if (precision == RTMI_F32 && s->dev.has_ext) return fail(RTMI_E_UNSUPPORTED, "rectangles / triangles / instances are FP64 only");
     double *d_rays = (double *)tmp.up(rays, (size_t)n * 7 * sizeof(double));
     double *d_out = (double *)tmp.alloc((size_t)n * 11 * sizeof(double));
     if (!d_rays || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
     int ppt, npt; size_t lds;
     if (precision == RTMI_F64) {
         lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
+        if (s->dev.has_ext) {
+            if (c->accel == RTMI_ACCEL_BVH) hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_BVH, true>), dim3(grid), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
+            else hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_SGPR_CULL, true>), dim3(grid), dim3(kBlock), 64, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
+        } else
         switch (c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant) {
         case SCAN_BVH: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_BVH>), dim3(grid), dim3(kBlock), std::max(lds, (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16), c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
         case SCAN_SGPR_CULL: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_SGPR_CULL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
@@ -1149,6 +1268,7 @@ RTMI_EXPORT int rtmi_probe_paths(rtmi_scene *s, int32_t precision, int32_t n, co
     PROBE_PROLOGUE(s)
     if (!rays || !keys || !out_rgb) return fail(RTMI_E_ARG, "NULL array");
     if (log && max_seg <= 0) return fail(RTMI_E_ARG, "log given but max_seg <= 0");
+    if (precision == RTMI_F32 && s->dev.has_ext) return fail(RTMI_E_UNSUPPORTED, "rectangles / triangles / instances are FP64 only");
     double *d_rays = (double *)tmp.up(rays, (size_t)n * 7 * sizeof(double));
     u64 *d_keys = (u64 *)tmp.up(keys, (size_t)n * sizeof(u64));
     double *d_rgb = (double *)tmp.alloc((size_t)n * 3 * sizeof(double));
@@ -1161,6 +1281,10 @@ RTMI_EXPORT int rtmi_probe_paths(rtmi_scene *s, int32_t precision, int32_t n, co
     int ppt, npt; size_t lds;
     if (precision == RTMI_F64) {
         lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
+        if (s->dev.has_ext) {
+            if (c->accel == RTMI_ACCEL_BVH) hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_BVH, true>), dim3(grid), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
+            else hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_SGPR_CULL, true>), dim3(grid), dim3(kBlock), 64, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
+        } else
         switch (c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant) {
         case SCAN_BVH: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_BVH>), dim3(grid), dim3(kBlock), std::max(lds, (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16), c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;
         case SCAN_SGPR_CULL: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_SGPR_CULL>), dim3(grid), dim3(kBlock), lds, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;

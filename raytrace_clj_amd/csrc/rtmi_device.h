@@ -35,6 +35,10 @@ struct DevScene {
     int n_big;               // primitives too large to bound usefully (sky dome, ground): always tested exactly
     int big_idx[16];
     float bvh_obound;        // rays starting outside [-obound, obound]^3 bypass the float traversal
+    // section 8(f3): rectangles / triangles and FlipNormals / Translate / RotateY instances (hitable.clj:269-511, 548-581)
+    int has_ext;             // any primitive kind > 2, any instance wrapper, any flip
+    const int *ext_info;     // [n_all][4]: kind, FlipNormals parity, first xform, xform count (outermost first)
+    const double *ext_xf;    // [n_xforms][4]: 0 | offset.xyz  (Translate)   or   1 | sin, cos, 0  (RotateY)
     const int *stat_orig;    // [n_static] index in the caller's Hitlist
     const double *mov_geom;  // [n_moving][9]  c0.xyz radius c1.xyz t0 t1
     const int *mov_orig;
@@ -559,6 +563,170 @@ __device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<double> &P, 
     }
 }
 
+// ==== section 8(f3): RectXY/XZ/YZ (hitable.clj:269-363), Triangle (548-571), FlipNormals (375-381), Translate (391-396),
+// ==== RotateY (410-450), Box = Hitlist of six (flipped) rectangles (491-511) -- FP64 only ==================================
+// Closest hit over MIXED kinds, any visiting order.  In the reference's sequential Hitlist scan (running t-max = closest
+// so far) a sphere replaces the current hit only if t < closest (hitable.clj:195) while rectangles and triangles use
+// t <= closest (hitable.clj:278, 564): among primitives tied at the minimal t the winner is the LAST "inclusive" one after
+// the first tied primitive, else the first.  F = lowest tied index, W = highest tied inclusive index: winner = max(F, W).
+struct ExtHit { double t; int F, W; bool any; };
+__device__ inline int ext_winner(const ExtHit &H) { return H.any ? max(H.F, H.W) : -1; }
+__device__ inline void ext_update(ExtHit &H, double t, int idx, bool incl) {
+    if (!H.any) { // H.t is the caller's t-max
+        if (incl ? (t <= H.t) : (t < H.t)) { H.t = t; H.F = idx; H.W = incl ? idx : -1; H.any = true; }
+    } else if (t < H.t) { H.t = t; H.F = idx; H.W = incl ? idx : -1; }
+    else if (t == H.t) { H.F = min(H.F, idx); if (incl) H.W = max(H.W, idx); }
+}
+
+struct LocalRay { double ox, oy, oz, dx, dy, dz; };
+// the ray as the innermost record sees it: Translate subtracts its offset from the origin (hitable.clj:394), RotateY
+// pre-rotates origin and direction (hitable.clj:423-429); outermost wrapper first
+__device__ inline LocalRay ext_local_ray(SceneRef sc, int first, int count, const Path<double> &P) {
+    LocalRay r = {P.ox, P.oy, P.oz, P.dx, P.dy, P.dz};
+    for (int k = 0; k < count; ++k) {
+        const double *q = sc.ext_xf + (size_t)(first + k) * 4;
+        if (q[0] == 0.0) { r.ox = r.ox - q[1]; r.oy = r.oy - q[2]; r.oz = r.oz - q[3]; }
+        else {
+            const double sn = q[1], cs = q[2];
+            const double ox = cs * r.ox - sn * r.oz, oz = sn * r.ox + cs * r.oz;
+            const double dx = cs * r.dx - sn * r.dz, dz = sn * r.dx + cs * r.dz;
+            r.ox = ox; r.oz = oz; r.dx = dx; r.dz = dz;
+        }
+    }
+    return r;
+}
+__device__ inline void cross3(double ax, double ay, double az, double bx, double by, double bz, double &x, double &y, double &z) {
+    x = ay * bz - az * by; y = az * bx - ax * bz; z = ax * by - ay * bx;
+}
+// Moeller-Trumbore exactly as hitable.clj:551-563 (one sided: det > 1e-8); returns false when there is no candidate
+__device__ inline bool tri_mt(const double *g, const LocalRay &r, double &u, double &v, double &t) {
+    const double e1x = g[3] - g[0], e1y = g[4] - g[1], e1z = g[5] - g[2];
+    const double e2x = g[6] - g[0], e2y = g[7] - g[1], e2z = g[8] - g[2];
+    double px, py, pz;
+    cross3(r.dx, r.dy, r.dz, e2x, e2y, e2z, px, py, pz);
+    const double det = dot3(e1x, e1y, e1z, px, py, pz);
+    if (!(det > 0.00000001)) return false;
+    const double inv_det = 1.0 / det;
+    const double tx = r.ox - g[0], ty = r.oy - g[1], tz = r.oz - g[2];
+    u = dot3(tx, ty, tz, px, py, pz) * inv_det;
+    if (!(u > 0.0 && u <= 1.0)) return false;
+    double qx, qy, qz;
+    cross3(tx, ty, tz, e1x, e1y, e1z, qx, qy, qz);
+    v = dot3(r.dx, r.dy, r.dz, qx, qy, qz) * inv_det;
+    if (!(v > 0.0 && u + v <= 1.0)) return false;
+    t = dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
+    return true;
+}
+__device__ inline void rect_axes(int kind, int &ax, int &ua, int &va) {
+    ax = kind == RTMI_PRIM_RECT_XY ? 2 : (kind == RTMI_PRIM_RECT_XZ ? 1 : 0);
+    ua = kind == RTMI_PRIM_RECT_YZ ? 1 : 0;
+    va = kind == RTMI_PRIM_RECT_XY ? 1 : 2;
+}
+
+// hit? of primitive idx (any kind, through its instance chain) folded into the any-order state
+__device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P, double tmin, ExtHit &H) {
+    const int4 info = reinterpret_cast<const int4 *>(sc.ext_info)[idx];
+    const LocalRay r = ext_local_ray(sc, info.z, info.w, P);
+    const double *g = sc.exact12 + (size_t)idx * 12;
+    const int kind = info.x;
+    if (kind <= RTMI_PRIM_MOVING) {
+        Prim4<double> s;
+        s.cx = g[0]; s.cy = g[1]; s.cz = g[2]; s.r2 = g[3];
+        if (kind == RTMI_PRIM_MOVING) {
+            const double t0 = g[7], t1 = g[8];
+            const double f = (P.time - t0) / (t1 - t0), omf = 1.0 - f;
+            s.cx = g[0] * omf + g[4] * f; s.cy = g[1] * omf + g[5] * f; s.cz = g[2] * omf + g[6] * f;
+        }
+        Path<double> L; L.ox = r.ox; L.oy = r.oy; L.oz = r.oz; L.dx = r.dx; L.dy = r.dy; L.dz = r.dz;
+        const double a = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
+        double bq, cq, disc;
+        sphere_test(s, L, a, bq, cq, disc);
+        if (disc >= 0.0 && !(tmin >= 0.0 && bq > 0.0 && cq > 0.0)) {
+            const double sq = ::sqrt(disc);
+            double t = (-bq - sq) / a;
+            if (!(t > tmin)) t = (-bq + sq) / a;
+            if (t > tmin) ext_update(H, t, idx, false);
+        }
+    } else if (kind <= RTMI_PRIM_RECT_YZ) {
+        int ax, ua, va;
+        rect_axes(kind, ax, ua, va);
+        const double o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+        const double t = (g[4] - o[ax]) / d[ax];
+        if (t >= tmin) {
+            const double x = o[ua] + t * d[ua], y = o[va] + t * d[va];
+            if (x >= g[0] && x <= g[2] && y >= g[1] && y <= g[3]) ext_update(H, t, idx, true);
+        }
+    } else {
+        double u, v, t;
+        if (tri_mt(g, r, u, v, t) && t >= tmin) ext_update(H, t, idx, true);
+    }
+}
+
+// the flat scan (FP32 cull + exact test) over all primitives
+__device__ inline void scan_all_cull_ext(SceneRef sc, const Path<double> &P, double a, double tmin, ExtHit &H) {
+    const int n = sc.n_all;
+    if (n <= 0) return;
+    const int last = n - 1;
+    const CullRay c = make_cull_ray(P, a, sc.cull_t_lo, sc.cull_t_hi);
+    for (int g = 0; g < n; g += 4) {
+        const CullGroup G = load_cull_group(sc.cull20, g >> 2);
+        const float d0 = cull_disc(G, 0, c), d1 = cull_disc(G, 1, c), d2 = cull_disc(G, 2, c), d3 = cull_disc(G, 3, c);
+        if (fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)) >= 0.0f) {
+            if (d0 >= 0.0f) ext_prim_test(sc, g, P, tmin, H);
+            if (d1 >= 0.0f && g + 1 <= last) ext_prim_test(sc, g + 1, P, tmin, H);
+            if (d2 >= 0.0f && g + 2 <= last) ext_prim_test(sc, g + 2, P, tmin, H);
+            if (d3 >= 0.0f && g + 3 <= last) ext_prim_test(sc, g + 3, P, tmin, H);
+        }
+    }
+}
+
+__device__ inline float ext_best_hi(const ExtHit &H) { return H.t < 3.0e38 ? float_up(H.t) : 3.4028235e38f; }
+
+__device__ inline void scan_bvh_ext(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, ExtHit &H) {
+    const float ox = (float)P.ox, oy = (float)P.oy, oz = (float)P.oz;
+    const float dx = (float)P.dx, dy = (float)P.dy, dz = (float)P.dz;
+    const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+    const float ob = sc.bvh_obound;
+    const bool safe = (fabsf(ox) <= ob) && (fabsf(oy) <= ob) && (fabsf(oz) <= ob) && (dmax < 1e15f) && (dmax > 1e-15f) &&
+                      (fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= 1e-12f * dmax) && (a > 1e-30) && (a < 1e30) &&
+                      (P.time >= sc.cull_t_lo) && (P.time <= sc.cull_t_hi) && (tmin > -1e30) && (tmin < 1e30);
+    if (!safe) { scan_all_cull_ext(sc, P, a, tmin, H); return; }
+    for (int k = 0; k < sc.n_big; ++k) ext_prim_test(sc, sc.big_idx[k], P, tmin, H);
+    int node = sc.bvh_root;
+    if (node == RTMI_BVH_EMPTY) return;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float cx = -ox * ix, cy = -oy * iy, cz = -oz * iz;
+    const float tmin_lo = -float_up(-tmin);
+    const int tid = threadIdx.x, stride = blockDim.x;
+    int sp = 0;
+    const float4 *nodes = reinterpret_cast<const float4 *>(sc.bvh_nodes);
+    float best_hi = ext_best_hi(H);
+    while (node != RTMI_BVH_EMPTY) {
+        while (node >= 0 && node != RTMI_BVH_EMPTY) {
+            const float4 n0 = nodes[(size_t)node * 4], n1 = nodes[(size_t)node * 4 + 1], n2 = nodes[(size_t)node * 4 + 2], n3 = nodes[(size_t)node * 4 + 3];
+            float tl, tr;
+            const bool hl = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, cx, cy, cz, ix, iy, iz, tmin_lo, best_hi, tl);
+            const bool hr = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, cx, cy, cz, ix, iy, iz, tmin_lo, best_hi, tr);
+            const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
+            if (hl && hr) {
+                const bool left_first = tl <= tr;
+                stack[sp * stride + tid] = left_first ? cr : cl;
+                ++sp;
+                node = left_first ? cl : cr;
+            } else if (hl) node = cl;
+            else if (hr) node = cr;
+            else if (sp > 0) { --sp; node = stack[sp * stride + tid]; }
+            else node = RTMI_BVH_EMPTY;
+        }
+        if (node != RTMI_BVH_EMPTY) {
+            ext_prim_test(sc, (~node) & 0x3fffffff, P, tmin, H);
+            best_hi = ext_best_hi(H);
+            if (sp > 0) { --sp; node = stack[sp * stride + tid]; }
+            else node = RTMI_BVH_EMPTY;
+        }
+    }
+}
+
 // hitable.clj:219-252 (MovingSphere.hit?): centre = lerp(c0, c1, (time-t0)/(t1-t0)) per ray.
 // Moving spheres are scanned after the static ones, so ties are resolved by original index.
 template <typename R>
@@ -623,6 +791,63 @@ template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path
         h.v = (theta + PI / R(2.0)) / PI;
     }
 }
+
+// the hit record of an f3 primitive: the innermost record's {:t :p :uv :normal} in ITS frame, then every wrapper's
+// outward step in reverse order -- RotateY post-rotates p and the normal (hitable.clj:441-446), Translate adds its offset
+// to p (hitable.clj:396), FlipNormals negates the normal (hitable.clj:380; negation commutes exactly with the rotation)
+__device__ inline void resolve_hit_ext(SceneRef sc, const Path<double> &P, double t, int orig, HitRec<double> &h) {
+    const int4 info = reinterpret_cast<const int4 *>(sc.ext_info)[orig];
+    const LocalRay r = ext_local_ray(sc, info.z, info.w, P);
+    const double *g = sc.exact12 + (size_t)orig * 12;
+    const int kind = info.x;
+    h.orig = orig; h.kind = kind; h.mat = sc.prim_mat[orig]; h.t = t;
+    double px = r.dx * t + r.ox, py = r.dy * t + r.oy, pz = r.dz * t + r.oz; // point-at-parameter of the LOCAL ray
+    double nx, ny, nz;
+    h.u = 0.0; h.v = 0.0;
+    if (kind <= RTMI_PRIM_MOVING) {
+        double cx = g[0], cy = g[1], cz = g[2];
+        if (kind == RTMI_PRIM_MOVING) {
+            const double t0 = g[7], t1 = g[8];
+            const double f = (P.time - t0) / (t1 - t0), omf = 1.0 - f;
+            cx = g[0] * omf + g[4] * f; cy = g[1] * omf + g[5] * f; cz = g[2] * omf + g[6] * f;
+        }
+        nx = px - cx; ny = py - cy; nz = pz - cz;
+        const double len = ::sqrt(dot3(nx, ny, nz, nx, ny, nz));
+        if (len > 0.0) { const double inv = 1.0 / len; nx = nx * inv; ny = ny * inv; nz = nz * inv; }
+        if (kind == RTMI_PRIM_UVSPHERE) {
+            const double PI = 3.141592653589793;
+            const double phi = ::atan2(nz, nx), theta = ::asin(ny);
+            h.u = 1.0 - (phi + PI) / (2.0 * PI);
+            h.v = (theta + PI / 2.0) / PI;
+        }
+    } else if (kind <= RTMI_PRIM_RECT_YZ) {
+        int ax, ua, va;
+        rect_axes(kind, ax, ua, va);
+        const double o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+        const double x = o[ua] + t * d[ua], y = o[va] + t * d[va];
+        h.u = (x - g[0]) / (g[2] - g[0]); h.v = (y - g[1]) / (g[3] - g[1]);
+        nx = ax == 0 ? 1.0 : 0.0; ny = ax == 1 ? 1.0 : 0.0; nz = ax == 2 ? 1.0 : 0.0;
+    } else {
+        double u = 0.0, v = 0.0, tt;
+        tri_mt(g, r, u, v, tt);
+        h.u = u; h.v = v;
+        cross3(g[3] - g[0], g[4] - g[1], g[5] - g[2], g[6] - g[0], g[7] - g[1], g[8] - g[2], nx, ny, nz); // not normalised (hitable.clj:570)
+    }
+    if (info.y) { nx = -nx; ny = -ny; nz = -nz; }
+    for (int k = info.w - 1; k >= 0; --k) {
+        const double *q = sc.ext_xf + (size_t)(info.z + k) * 4;
+        if (q[0] == 0.0) { px = px + q[1]; py = py + q[2]; pz = pz + q[3]; }
+        else {
+            const double sn = q[1], cs = q[2];
+            const double rx = cs * px + sn * pz, rz = (-(sn * px)) + cs * pz;
+            const double mx = cs * nx + sn * nz, mz = (-(sn * nx)) + cs * nz;
+            px = rx; pz = rz; nx = mx; nz = mz;
+        }
+    }
+    h.px = px; h.py = py; h.pz = pz; h.nx = nx; h.ny = ny; h.nz = nz;
+}
+template <typename R, bool EXT> __device__ inline void resolve_any(SceneRef sc, const Path<R> &P, R t, int orig, HitRec<R> &h) { resolve_hit<R>(sc, P, t, orig, h); }
+template <> __device__ inline void resolve_any<double, true>(SceneRef sc, const Path<double> &P, double t, int orig, HitRec<double> &h) { resolve_hit_ext(sc, P, t, orig, h); }
 
 // Shader.scatter + Shader.emitted for the hit record, and the atten/accum update of core.clj:27-39.
 // Returns true when the path continues (the `recur` of core.clj:30) with P holding the scattered ray.
@@ -704,11 +929,11 @@ template <typename R> __device__ inline bool scatter_emit(SceneRef sc, Path<R> &
 }
 
 // One iteration of `color`'s loop after hit? has returned (core.clj:25-41).
-template <typename R>
+template <typename R, bool EXT = false>
 __device__ inline bool shade_segment(SceneRef sc, Path<R> &P, R t, int orig, SegLog *lg) {
     if (orig < 0) return false; // miss: (color) returns accum, core.clj:40-41
     HitRec<R> h;
-    resolve_hit<R>(sc, P, t, orig, h);
+    resolve_any<R, EXT>(sc, P, t, orig, h);
     const bool scat = scatter_emit<R>(sc, P, h, nullptr);
     if (lg && lg->n < lg->max_seg) {
         double *q = lg->rec + (size_t)lg->n * RTMI_SEG_REC;

@@ -15,6 +15,8 @@ from . import shader as shad
 from . import texture as tex
 
 PRIM_SPHERE, PRIM_UVSPHERE, PRIM_MOVING = 0, 1, 2
+PRIM_RECT_XY, PRIM_RECT_XZ, PRIM_RECT_YZ, PRIM_TRIANGLE = 3, 4, 5, 6
+XFORM_TRANSLATE, XFORM_ROTATE_Y = 0, 1
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
 TEX_CONSTANT, TEX_UVGRADIENT, TEX_CHECKER = 0, 1, 2
 CAM_PINHOLE, CAM_THINLENS = 0, 1
@@ -40,26 +42,45 @@ class FlatScene:
         self.tex_child = np.zeros((0, 2), np.int32)
         self.cam_kind = CAM_PINHOLE
         self.cam = np.zeros(24, np.float64)
+        # instancing (hitable.clj:375-486): per primitive, the parity of the FlipNormals wrappers around it and the chain of
+        # Translate / RotateY wrappers, outermost first, as a slice of the xform table
+        self.prim_flip = np.zeros(0, np.int32)
+        self.prim_xform = np.zeros((0, 2), np.int32)   # first, count
+        self.xform_kind = np.zeros(0, np.int32)
+        self.xform_param = np.zeros((0, 3), np.float64)  # translate: offset.xyz | rotate-y: sin, cos, 0
 
     @property
     def n_prims(self):
         return len(self.prim_kind)
 
 
-def _leaves(world, out, seen):
+_LEAF_TYPES = (hit.Sphere, hit.UVSphere, hit.MovingSphere, hit.RectXY, hit.RectXZ, hit.RectYZ, hit.Triangle)
+
+
+def _leaves(world, out, seen, chain=(), flip=0):
+    """out gets (leaf, chain, flip): chain = the Translate/RotateY wrappers around the leaf, outermost first"""
     if isinstance(world, hit.Hitlist):
         for it in world.items:
-            _leaves(it, out, seen)
+            _leaves(it, out, seen, chain, flip)
     elif isinstance(world, hit.bvh_node):
-        _leaves(world.left, out, seen)
-        _leaves(world.right, out, seen)
-    elif isinstance(world, (hit.Sphere, hit.UVSphere, hit.MovingSphere)):
-        if id(world) not in seen:
-            seen.add(id(world))
-            out.append(world)
+        _leaves(world.left, out, seen, chain, flip)
+        _leaves(world.right, out, seen, chain, flip)
+    elif isinstance(world, hit.Box):
+        _leaves(world.sides, out, seen, chain, flip)
+    elif isinstance(world, hit.FlipNormals):
+        _leaves(world.item, out, seen, chain, flip ^ 1)
+    elif isinstance(world, hit.Translate):
+        _leaves(world.item, out, seen, chain + ((XFORM_TRANSLATE, tuple(float(v) for v in world.offset)),), flip)
+    elif isinstance(world, hit.RotateY):
+        _leaves(world.obj, out, seen, chain + ((XFORM_ROTATE_Y, (float(world.sin_theta), float(world.cos_theta), 0.0)),), flip)
+    elif isinstance(world, _LEAF_TYPES):
+        key = (id(world), chain, flip)  # the same record under two different instances is two primitives
+        if key not in seen:
+            seen.add(key)
+            out.append((world, chain, flip))
     elif isinstance(world, (list, tuple)):
         for it in world:
-            _leaves(it, out, seen)
+            _leaves(it, out, seen, chain, flip)
     else:
         raise UnsupportedOnGpuPath("%s is not supported on the GPU path" % type(world).__name__)
 
@@ -120,15 +141,40 @@ def flatten(scene_or_world, camera=None):
     fs.prim_kind = np.zeros(n, np.int32)
     fs.prim_geom = np.zeros((n, PRIM_STRIDE), np.float64)
     fs.prim_mat = np.zeros(n, np.int32)
-    for i, o in enumerate(leaves):
+    fs.prim_flip = np.zeros(n, np.int32)
+    fs.prim_xform = np.zeros((n, 2), np.int32)
+    chains, xk, xp = {}, [], []
+    for i, (o, chain, flip) in enumerate(leaves):
         g = fs.prim_geom[i]
         if isinstance(o, hit.MovingSphere):
             fs.prim_kind[i] = PRIM_MOVING
             g[0:3], g[3], g[4:7], g[7], g[8] = o.center0, o.radius, o.center1, o.t0, o.t1
-        else:
+        elif isinstance(o, (hit.Sphere, hit.UVSphere)):
             fs.prim_kind[i] = PRIM_UVSPHERE if isinstance(o, hit.UVSphere) else PRIM_SPHERE
             g[0:3], g[3], g[4:7], g[7], g[8] = o.center, o.radius, o.center, 0.0, 1.0
+        elif isinstance(o, hit.RectXY):
+            fs.prim_kind[i] = PRIM_RECT_XY
+            g[0:5] = o.x0, o.y0, o.x1, o.y1, o.k
+        elif isinstance(o, hit.RectXZ):
+            fs.prim_kind[i] = PRIM_RECT_XZ
+            g[0:5] = o.x0, o.z0, o.x1, o.z1, o.k
+        elif isinstance(o, hit.RectYZ):
+            fs.prim_kind[i] = PRIM_RECT_YZ
+            g[0:5] = o.y0, o.z0, o.y1, o.z1, o.k
+        else:
+            fs.prim_kind[i] = PRIM_TRIANGLE
+            g[0:3], g[3:6], g[6:9] = o.v0, o.v1, o.v2
         fs.prim_mat[i] = materials.get(o.material, build_mat)
+        fs.prim_flip[i] = flip
+        if chain:
+            if chain not in chains:
+                chains[chain] = (len(xk), len(chain))
+                for kind, params in chain:
+                    xk.append(kind)
+                    xp.append(params)
+            fs.prim_xform[i] = chains[chain]
+    fs.xform_kind = np.array(xk, np.int32)
+    fs.xform_param = np.array(xp, np.float64).reshape(-1, 3)
     fs.mat_kind = np.array([r[0] for r in materials.rows], np.int32)
     fs.mat_tex = np.array([r[1] for r in materials.rows], np.int32)
     fs.mat_param = np.array([r[2] for r in materials.rows], np.float64)

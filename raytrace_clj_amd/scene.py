@@ -5,8 +5,9 @@ make_random_scene = the Shirley cover scene (scene.clj:318-412); make_two_sphere
 The reference draws scene randomness from the unseeded clojure.core/rand; here every (rand) is the
 next value of a seeded SplitMix64 stream, consumed in the reference's evaluation order (per grid cell:
 centre x, centre z, choose-mat, then the material's own draws; cells failing the :when filter still
-consume their three draws).  The other scene functions of scene.clj use records outside the GPU
-path's scope (rectangles, boxes, media, triangles, Perlin / image textures)."""
+consume their three draws).  make_two_triangles = scene.clj:80-114 and make_cornell_box (classic) = scene.clj:230-316 use the section-8(f3) records
+(rectangles, boxes, instances, triangles).  The remaining scene functions need Perlin / image textures or ConstantMedium,
+which are outside the GPU path's scope."""
 import math
 
 import numpy as np
@@ -41,6 +42,51 @@ def make_two_spheres(nx, ny, seed=SCENE_SEED):
             hit.uv_sphere(center=vec3(0, 2, 0), radius=2,
                           material=shad.lambertian(albedo=tex.uv_gradient(co=vec3(0, 1, 0), cu=vec3(0, 1, 1),
                                                                           cv=vec3(1, 0, 1), cuv=vec3(1, 0, 0)))),
+        ], 0.0, 1.0, rng),
+    }
+
+
+def make_two_triangles(nx, ny, seed=SCENE_SEED):
+    """two triangles, view down the -z axis -- scene.clj:80-114"""
+    rng = SplitMix64(seed)
+    white = tex.constant(color=vec3(0.9, 0.9, 0.9))
+    red = tex.constant(color=vec3(0.9, 0, 0))
+    return {
+        "camera": cam.thin_lens_camera(lookfrom=vec3(1, 1, -10), lookat=vec3(1, 1, 0), vup=vec3(0, 1, 0), vfov=20,
+                                       aspect=_aspect(nx, ny), aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0),
+        "world": hit.make_bvh([
+            hit.sphere(center=vec3(0, 0, 0), radius=1000, material=shad.diffuse_light(tex=tex.constant(color=0.8 * vec3(0.3, 0.5, 0.8)))),
+            hit.triangle(v0=vec3(0, 0, 0), v1=vec3(0, 1, 0), v2=vec3(1, 0, 0), material=shad.lambertian(albedo=red)),
+            hit.triangle(v0=vec3(1, 1, 0), v1=vec3(1, 2, 0), v2=vec3(2, 1, 0), material=shad.lambertian(albedo=white)),
+        ], 0.0, 1.0, rng),
+    }
+
+
+def make_cornell_box(nx, ny, classic=True, seed=SCENE_SEED):
+    """classic cornell box -- scene.clj:230-316.  classic=False (the foggy boxes) needs ConstantMedium, which the GPU
+    path does not implement."""
+    if not classic:
+        from .flatten import UnsupportedOnGpuPath
+        raise UnsupportedOnGpuPath("ConstantMedium (hitable.clj:516-543) is not supported on the GPU path")
+    rng = SplitMix64(seed)
+    red = shad.lambertian(albedo=tex.constant(color=vec3(0.65, 0.05, 0.05)))
+    white = shad.lambertian(albedo=tex.constant(color=vec3(0.73, 0.73, 0.73)))
+    green = shad.lambertian(albedo=tex.constant(color=vec3(0.12, 0.45, 0.15)))
+    light = shad.diffuse_light(tex=tex.constant(color=vec3(7, 7, 7)))
+    return {
+        "camera": cam.thin_lens_camera(lookfrom=vec3(278, 278, -800), lookat=vec3(278, 278, 0), vup=vec3(0, 1, 0), vfov=40,
+                                       aspect=_aspect(nx, ny), aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0),
+        "world": hit.make_bvh([
+            hit.flip_normals(item=hit.rect_yz(y0=0, z0=0, y1=555, z1=555, k=555, material=green)),
+            hit.rect_yz(y0=0, z0=0, y1=555, z1=555, k=0, material=red),
+            hit.rect_xz(x0=213, z0=227, x1=343, z1=332, k=554, material=light),
+            hit.flip_normals(item=hit.rect_xz(x0=0, z0=0, x1=555, z1=555, k=555, material=white)),
+            hit.rect_xz(x0=0, z0=0, x1=555, z1=555, k=0, material=white),
+            hit.flip_normals(item=hit.rect_xy(x0=0, y0=0, x1=555, y1=555, k=555, material=white)),
+            hit.translate(item=hit.rotate_y(item=hit.box(p0=vec3(0, 0, 0), p1=vec3(165, 165, 165), material=white), theta=-18.0),
+                          offset=vec3(130, 0, 65)),
+            hit.translate(item=hit.rotate_y(item=hit.box(p0=vec3(0, 0, 0), p1=vec3(165, 330, 165), material=white), theta=15.0),
+                          offset=vec3(265, 0, 295)),
         ], 0.0, 1.0, rng),
     }
 

@@ -427,6 +427,91 @@ def test_random_scenes_match_oracle(oracle, seed):
     ctx.close()
 
 
+# ---- section 8(f3): rectangles, triangles, FlipNormals / Translate / RotateY instances, Box ----------------------------------
+def _f3_scenes():
+    H, S, T = r.hitable, r.shader, r.texture
+    yield "cornell", r.scene.make_cornell_box(64, 64)
+    yield "triangles", r.scene.make_two_triangles(64, 32)
+    rng = np.random.default_rng(17)
+    light = S.diffuse_light(tex=T.constant(color=vec3(3, 3, 3)))
+    items = [H.sphere(center=vec3(0, 0, 0), radius=300.0, material=light)]
+    for k in range(40):
+        m = [S.lambertian(albedo=T.constant(color=vec3(*rng.random(3)))), S.metal(albedo=T.constant(color=vec3(*rng.random(3))), fuzz=float(rng.random())),
+             S.dielectric(ri=1.5), S.lambertian(albedo=T.checkerboard(tex0=T.constant(color=vec3(0, 0, 0)), tex1=T.constant(color=vec3(1, 1, 1)), scale=2.0))][k % 4]
+        c = vec3(*rng.normal(0, 8, 3))
+        kind = k % 5
+        if kind == 0:
+            o = H.box(p0=c, p1=c + vec3(*(1 + 3 * rng.random(3))), material=m)
+        elif kind == 1:
+            o = H.triangle(v0=c, v1=c + vec3(*rng.normal(0, 3, 3)), v2=c + vec3(*rng.normal(0, 3, 3)), material=m)
+        elif kind == 2:
+            o = H.rect_xz(x0=c[0], z0=c[2], x1=c[0] + 4, z1=c[2] + 3, k=c[1], material=m)
+        elif kind == 3:
+            o = H.sphere(center=c, radius=1.5, material=m)
+        else:
+            o = H.moving_sphere(center0=c, t0=0.0, center1=c + vec3(0, 1, 0), t1=1.0, radius=1.0, material=m)
+        w = k % 4
+        if w == 1:
+            o = H.translate(item=o, offset=vec3(*rng.normal(0, 5, 3)))
+        elif w == 2:
+            o = H.rotate_y(item=o, theta=float(rng.uniform(-180, 180)))
+        elif w == 3:
+            o = H.translate(item=H.rotate_y(item=H.flip_normals(item=o), theta=float(rng.uniform(-90, 90))), offset=vec3(*rng.normal(0, 5, 3)))
+        items.append(o)
+    camera = r.camera.thin_lens_camera(lookfrom=vec3(3, 6, -40), lookat=vec3(0, 0, 0), vup=vec3(0, 1, 0), vfov=50, aspect=2.0, aperture=0.2,
+                                       focus_dist=40.0, t0=0.0, t1=1.0)
+    yield "instanced-mix", {"camera": camera, "world": H.make_bvh(items, 0.0, 1.0)}
+
+
+def test_f3_scenes_match_nested_oracle(oracle):
+    """the device (flattened primitives + transform chains, BVH and flat scan) against the oracle evaluating the NESTED
+    records the way the reference does (wrappers, Box's inner Hitlist, bvh-node slab descent)"""
+    from oracle.tree import flatten_with_tree
+    for name, sc in _f3_scenes():
+        f = flatten_with_tree(sc)
+        nx, ny, ns = (48, 48, 8) if name == "cornell" else (64, 32, 6)
+        exp_lin, exp_q, exp_cnt = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, nthreads=16)
+        rng = np.random.default_rng(3)
+        n = 4096
+        keys = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+        cam = oracle.probe_camera(f, rng.random((n, 2)), keys)
+        ctr0 = int(cam[:, 7].max())
+        ergb, enseg, elog, _ = oracle.probe_paths(f, cam[:, :7], keys, depth=50, ctr0=ctr0, max_seg=8)
+        ehit = oracle.probe_hit(f, cam[:, :7])
+        ctx = core.Context(0)
+        ds = core.DeviceScene(f, ctx=ctx)
+        for accel in (1, 0):
+            ctx.set_option("accel", accel)
+            hit = ds.probe_hit(cam[:, :7])
+            assert np.array_equal(hit[:, :9], ehit[:, :9]), (name, accel)
+            assert np.allclose(hit[:, 9:], ehit[:, 9:], atol=1e-14, rtol=0)
+            rgb, nseg, log, _ = ds.probe_paths(cam[:, :7], keys, depth=50, ctr0=ctr0, max_seg=8)
+            assert np.array_equal(nseg, enseg) and np.array_equal(log, elog), (name, accel)
+            assert np.allclose(rgb, ergb, atol=1e-11, rtol=0)
+            lin, q, cnt = ds.render(nx, ny, ns)
+            assert np.array_equal(cnt, exp_cnt) and rms(lin, exp_lin) < 1e-12, (name, accel)
+            assert np.abs(q.astype(int) - exp_q.astype(int)).max() <= 1
+        with pytest.raises(core.RtmiError) as e:
+            ds.render(nx, ny, ns, precision="f32")
+        assert e.value.code == -3
+        ds.close()
+        ctx.close()
+
+
+def test_f3_cornell_full_size_bvh_equals_flat():
+    nx, ny, ns = 400, 400, 16
+    ctx = core.Context(0)
+    ds = core.DeviceScene(r.scene.make_cornell_box(nx, ny), ctx=ctx)
+    ctx.set_option("accel", 0)
+    flat = ds.render(nx, ny, ns)
+    ctx.set_option("accel", 1)
+    bvh = ds.render(nx, ny, ns)
+    ds.close(); ctx.close()
+    for a, b in zip(flat, bvh):
+        assert np.array_equal(a, b)
+    assert flat[0].mean() > 0.02
+
+
 def test_cull_handles_degenerate_rays():
     """rays the FP32 image cannot represent (huge / tiny / zero / NaN) must fall through to the exact test"""
     s = r.hitable.sphere(center=vec3(0, 0, 0), radius=1.0, material=MATERIAL)

@@ -272,3 +272,87 @@ def test_render_region_and_threads(oracle, cover_small):
     assert not np.array_equal(other, full)
     # row 0 is the TOP of the picture: sky (bright, blue-ish) above ground
     assert full[0].mean() > 0.3
+
+
+# ---- section 8(f3) records: no test in the reference covers them (parity unpinned by the reference); analytic KATs -------------
+def nested(world):
+    from oracle.tree import attach_tree
+    f = fl.flatten(world, r.camera.PinholeCamera(*(np.zeros(3),) * 4))
+    return attach_tree(f, world)
+
+
+def test_f3_rectangles(oracle):
+    H = r.hitable
+    for ctor, o, d, p, n, uv in [
+        (lambda: H.rect_xy(x0=-1, y0=-2, x1=3, y1=2, k=5, material=MATERIAL), vec3(1, 0, 0), vec3(0, 0, 1), (1, 0, 5), (0, 0, 1), (0.5, 0.5)),
+        (lambda: H.rect_xz(x0=-1, z0=-2, x1=3, z1=2, k=5, material=MATERIAL), vec3(1, 0, 1), vec3(0, 2, 0), (1, 5, 1), (0, 1, 0), (0.5, 0.75)),
+        (lambda: H.rect_yz(y0=-1, z0=-2, y1=3, z1=2, k=5, material=MATERIAL), vec3(0, 2, -1), vec3(1, 0, 0), (5, 2, -1), (1, 0, 0), (0.75, 0.25))]:
+        w = nested(H.hitlist(items=[ctor()]))
+        h = oracle.probe_hit(w, ray7(o, d), 0.001, FLT_MAX)[0]
+        assert h[0] == 1 and tuple(h[3:6]) == p and tuple(h[6:9]) == n and tuple(h[9:11]) == uv
+        flipped = nested(H.hitlist(items=[H.flip_normals(item=ctor())]))
+        assert tuple(oracle.probe_hit(flipped, ray7(o, d), 0.001, FLT_MAX)[0, 6:9]) == tuple(-x for x in n)
+        assert oracle.probe_hit(w, ray7(o, -d), 0.001, FLT_MAX)[0, 0] == 0  # behind the origin
+    # inclusive interval and extents (hitable.clj:278,281-282): t == t-max and a hit exactly on the edge count
+    w = nested(H.hitlist(items=[H.rect_xy(x0=0, y0=0, x1=1, y1=1, k=2, material=MATERIAL)]))
+    assert oracle.probe_hit(w, ray7(vec3(1, 1, 0), vec3(0, 0, 1)), 0.0, 2.0)[0, 0] == 1
+    assert oracle.probe_hit(w, ray7(vec3(1.0000001, 1, 0), vec3(0, 0, 1)), 0.0, 2.0)[0, 0] == 0
+    # a rectangle tied with an EARLIER sphere wins (<=), a sphere tied with an earlier rectangle does not (<)
+    s = H.sphere(center=vec3(0.5, 0.5, 3), radius=1.0, material=MATERIAL)
+    rect = H.rect_xy(x0=0, y0=0, x1=1, y1=1, k=2, material=MATERIAL)
+    ray = ray7(vec3(0.5, 0.5, 0), vec3(0, 0, 1))
+    assert oracle.probe_hit(nested(H.hitlist(items=[s, rect])), ray, 0.001, FLT_MAX)[0, 1] == 1
+    assert oracle.probe_hit(nested(H.hitlist(items=[rect, s])), ray, 0.001, FLT_MAX)[0, 1] == 0
+
+
+def test_f3_triangle(oracle):
+    H = r.hitable
+    tri = H.triangle(v0=vec3(0, 0, 0), v1=vec3(0, 1, 0), v2=vec3(1, 0, 0), material=MATERIAL)  # as make-two-triangles (scene.clj:103-107)
+    w = nested(H.hitlist(items=[tri]))
+    h = oracle.probe_hit(w, ray7(vec3(0.25, 0.25, -10), vec3(0, 0, 1)), 0.001, FLT_MAX)[0]
+    assert h[0] == 1 and h[2] == 10.0 and tuple(h[3:6]) == (0.25, 0.25, 0.0) and tuple(h[9:11]) == (0.25, 0.25)
+    assert tuple(h[6:9]) == (0.0, 0.0, -1.0)  # cross(v0v1, v0v2), not normalised
+    assert oracle.probe_hit(w, ray7(vec3(0.25, 0.25, 10), vec3(0, 0, -1)), 0.001, FLT_MAX)[0, 0] == 0  # one sided (det > 1e-8)
+    assert oracle.probe_hit(w, ray7(vec3(0.75, 0.75, -10), vec3(0, 0, 1)), 0.001, FLT_MAX)[0, 0] == 0  # u + v > 1
+
+
+def test_f3_instances_and_box(oracle):
+    H = r.hitable
+    b = H.box(p0=vec3(0, 0, 0), p1=vec3(2, 2, 2), material=MATERIAL)
+    w = nested(H.hitlist(items=[b]))
+    h = oracle.probe_hit(w, ray7(vec3(1, 1, -5), vec3(0, 0, 1)), 0.001, FLT_MAX)[0]
+    assert h[0] == 1 and h[2] == 5.0 and tuple(h[6:9]) == (0.0, 0.0, -1.0)  # near face z = 0 is the flipped RectXY
+    h = oracle.probe_hit(w, ray7(vec3(1, 1, 1), vec3(0, 0, 1)), 0.001, FLT_MAX)[0]
+    assert h[2] == 1.0 and tuple(h[6:9]) == (0.0, 0.0, 1.0)
+    moved = H.translate(item=b, offset=vec3(10, 0, 0))
+    h = oracle.probe_hit(nested(H.hitlist(items=[moved])), ray7(vec3(11, 1, -5), vec3(0, 0, 1)), 0.001, FLT_MAX)[0]
+    assert h[0] == 1 and h[2] == 5.0 and tuple(h[3:6]) == (11.0, 1.0, 0.0)
+    rot = H.rotate_y(item=H.rect_xy(x0=-1, y0=-1, x1=1, y1=1, k=0, material=MATERIAL), theta=90.0)  # z = 0 plane -> x = 0 plane
+    h = oracle.probe_hit(nested(H.hitlist(items=[rot])), ray7(vec3(-5, 0.5, 0.25), vec3(1, 0, 0)), 0.001, FLT_MAX)[0]
+    assert h[0] == 1 and abs(h[2] - 5.0) < 1e-12 and np.allclose(h[3:6], (0, 0.5, 0.25), atol=1e-12) and np.allclose(np.abs(h[6:9]), (1, 0, 0), atol=1e-12)
+    # host mirror bboxes (hitable.clj:292-294, 397-400, 452-481, 572-577)
+    assert np.allclose(moved.bbox(0, 1).vmin, (10, 0, 0)) and np.allclose(moved.bbox(0, 1).vmax, (12, 2, 2))
+    rb = rot.bbox(0, 1)
+    assert np.allclose(rb.vmin, (-1e-4, -1, -1), atol=1e-9) and np.allclose(rb.vmax, (1e-4, 1, 1), atol=1e-9)
+
+
+def test_f3_flatten_chains():
+    f = fl.flatten(r.scene.make_cornell_box(64, 64))
+    assert f.n_prims == 18 and (f.prim_kind >= 3).all() and f.prim_flip.sum() == 9
+    assert len(f.xform_kind) == 4 and list(f.xform_kind) == [0, 1, 0, 1] and (f.prim_xform[:, 1] == 2).sum() == 12
+    with pytest.raises(r.UnsupportedOnGpuPath):
+        r.scene.make_cornell_box(64, 64, classic=False)
+    # the same Box instanced twice is two sets of primitives
+    b = r.hitable.box(p0=vec3(0, 0, 0), p1=vec3(1, 1, 1), material=MATERIAL)
+    f2 = fl.flatten(r.hitable.hitlist(items=[r.hitable.translate(item=b, offset=vec3(5, 0, 0)), r.hitable.translate(item=b, offset=vec3(-5, 0, 0))]), None)
+    assert f2.n_prims == 12 and len(f2.xform_kind) == 2
+
+
+def test_f3_cornell_and_triangles_render(oracle):
+    from oracle.tree import flatten_with_tree
+    lin, q, cnt = oracle.render(flatten_with_tree(r.scene.make_cornell_box(32, 32)), 32, 32, 16, 50, 7, nthreads=8)
+    # camera u = vup x w = (-1, 0, 0): the image's left is world +x, i.e. the green wall (x = 555); the red wall (x = 0) is on the right
+    assert np.isfinite(lin).all() and lin.mean() > 0.02
+    assert lin[:, :8, 1].mean() > lin[:, :8, 0].mean() and lin[:, -8:, 0].mean() > lin[:, -8:, 1].mean()
+    lin2, _, _ = oracle.render(flatten_with_tree(r.scene.make_two_triangles(32, 16)), 32, 16, 8, 50, 7, nthreads=8)
+    assert lin2[:, :, 2].mean() > lin2[:, :, 0].mean()  # blue-ish light dome dominates
