@@ -25,6 +25,8 @@ CONFIGS = {
     "C3": (1920, 1080, 256, 50, False, (0.8, 0.95)),
     "C4": (3840, 2160, 512, 11, False, (0.8, 0.95)),
     "C5": (1920, 1080, 4096, 11, False, (0.1, 0.2)),
+    # section 8(f3): the classic Cornell box (scene.clj:230-316), 18 rectangles through Translate/RotateY/FlipNormals
+    "CB": (600, 600, 256, 0, False, None),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6     # vector FP64 (spec)
@@ -98,8 +100,11 @@ def main():
 
     nx, ny, ns1, n, moving, mix = CONFIGS[args.config]
     ns = ns1 * world  # weak scaling: per-GPU work fixed
-    scene = r.scene.make_random_scene(nx, ny, n, moving, mix=mix)
+    scene = r.scene.make_cornell_box(nx, ny) if args.config == "CB" else r.scene.make_random_scene(nx, ny, n, moving, mix=mix)
     flat = r.flatten.flatten(scene)
+    if args.config == "CB":  # the CPU baseline evaluates the nested records like the reference does
+        from oracle.tree import attach_tree
+        attach_tree(flat, scene["world"])
     ctx = r.Context(local_rank, timing=True)
     if args.blocks_per_cu:
         ctx.set_option("blocks_per_cu", args.blocks_per_cu)
@@ -183,9 +188,12 @@ def main():
             "metric": "Msamples/sec (nx*ny*ns)", "value": res["value"], "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "%s: %dx%dx%dspp Shirley cover scene n=%d (%d spheres%s), depth 50, thin-lens camera, "
-                                   "seeded counter RNG; accel=%s; tiles dealt round-robin to %d GPU(s)" % (
-                                       args.config, nx, ny, ns, n, n_prims, ", moving" if moving else "", main_accel, world),
+            "config": {"workload": ("%s: %dx%dx%dspp classic Cornell box (%d rectangles via Translate/RotateY/FlipNormals), depth 50, "
+                                    "seeded counter RNG; accel=%s; tiles dealt round-robin to %d GPU(s)" % (args.config, nx, ny, ns, n_prims, main_accel, world))
+                       if args.config == "CB" else
+                       "%s: %dx%dx%dspp Shirley cover scene n=%d (%d spheres%s), depth 50, thin-lens camera, "
+                       "seeded counter RNG; accel=%s; tiles dealt round-robin to %d GPU(s)" % (
+                           args.config, nx, ny, ns, n, n_prims, ", moving" if moving else "", main_accel, world),
                        "nx": nx, "ny": ny, "ns": ns, "spheres": n_prims, "depth": 50, "accel": main_accel,
                        "segments_per_sample": round(res["segments"] / samples, 4)},
             "roofline": res["roofline"],

@@ -13,7 +13,8 @@
             [raytrace-clj.scene :as scene])
   (:import [com.sun.jna Function Pointer Memory]
            [com.sun.jna.ptr PointerByReference]
-           [raytrace_clj.hitable Hitlist bvh_node Sphere UVSphere MovingSphere]
+           [raytrace_clj.hitable Hitlist bvh_node Sphere UVSphere MovingSphere RectXY RectXZ RectYZ Triangle
+            FlipNormals Translate RotateY Box]
            [raytrace_clj.shader Lambertian Metal Dielectric DiffuseLight]
            [raytrace_clj.texture Constant UVGradient Checkerboard]
            [raytrace_clj.camera PinholeCamera ThinLensCamera]))
@@ -41,25 +42,38 @@
 ;;; flattener: protocol extended onto the reference's records (field names as in the reference)
 ;;; ---------------------------------------------------------------------------------------------
 
+(defn- v3 [v] [(mat/mget v 0) (mat/mget v 1) (mat/mget v 2)])
+
 (defprotocol GpuLeaves
-  (leaves [this] "the Sphere/UVSphere/MovingSphere records below this Hitable, in Hitlist order"))
+  (leaves [this chain flip]
+    "[{:leaf record :chain [[kind a b c] ...] :flip 0|1} ...] below this Hitable, in Hitlist order; chain = the
+    Translate / RotateY wrappers around the leaf, outermost first (kind 0 = translate offset.xyz, 1 = rotate-y sin cos 0)"))
+
+(defn- leaf [this chain flip] [{:leaf this :chain chain :flip flip}])
 
 (extend-protocol GpuLeaves
-  Hitlist      (leaves [this] (mapcat leaves (:items this)))      ; hitable.clj:15-26
-  bvh_node     (leaves [this] (concat (leaves (:left this)) (leaves (:right this)))) ; hitable.clj:97-105
-  Sphere       (leaves [this] [this])
-  UVSphere     (leaves [this] [this])
-  MovingSphere (leaves [this] [this])
-  Object       (leaves [this] (throw (ex-info (str (type this) " is not supported on the GPU path")
-                                              {:unsupported-on-gpu-path (type this)}))))
+  Hitlist      (leaves [this c f] (mapcat #(leaves % c f) (:items this)))                       ; hitable.clj:15-26
+  bvh_node     (leaves [this c f] (concat (leaves (:left this) c f) (leaves (:right this) c f))) ; hitable.clj:97-105
+  Box          (leaves [this c f] (leaves (:sides this) c f))                                    ; hitable.clj:491-494
+  FlipNormals  (leaves [this c f] (leaves (:item this) c (bit-xor f 1)))                         ; hitable.clj:375-381
+  Translate    (leaves [this c f] (leaves (:item this) (conj c (into [0.0] (v3 (:offset this)))) f)) ; hitable.clj:391-396
+  RotateY      (leaves [this c f] (leaves (:obj this) (conj c [1.0 (:sin-theta this) (:cos-theta this) 0.0]) f)) ; :410-450
+  Sphere       (leaves [this c f] (leaf this c f))
+  UVSphere     (leaves [this c f] (leaf this c f))
+  MovingSphere (leaves [this c f] (leaf this c f))
+  RectXY       (leaves [this c f] (leaf this c f))
+  RectXZ       (leaves [this c f] (leaf this c f))
+  RectYZ       (leaves [this c f] (leaf this c f))
+  Triangle     (leaves [this c f] (leaf this c f))
+  Object       (leaves [this c f] (throw (ex-info (str (type this) " is not supported on the GPU path")
+                                                  {:unsupported-on-gpu-path (type this)}))))
 
-(defn- dedup-by-identity
-  "a one-item make-bvh stores the same child twice (hitable.clj:113-114)"
+(defn- dedup-leaves
+  "a one-item make-bvh stores the same child twice (hitable.clj:113-114): drop repeats of the same record under the
+  same instance chain (the same record under two different instances is two primitives)"
   [xs]
-  (let [seen (java.util.IdentityHashMap.)]
-    (filterv #(nil? (.put seen % true)) xs)))
-
-(defn- v3 [v] [(mat/mget v 0) (mat/mget v 1) (mat/mget v 2)])
+  (let [seen (java.util.HashSet.)]
+    (filterv #(.add seen [(System/identityHashCode (:leaf %)) (:chain %) (:flip %)]) xs)))
 
 (defn- intern! [table obj build]
   ;; table: atom {:ids IdentityHashMap, :rows []}; children are interned first
@@ -89,12 +103,18 @@
       DiffuseLight {:kind 3 :tex (tex (:tex m)) :param 0.0}
       (throw (ex-info (str (type m) " is not supported on the GPU path") {:unsupported-on-gpu-path (type m)})))))
 
+(defn- pad9 [xs] (take 9 (concat (map double xs) (repeat 0.0))))
+
 (defn- prim-row [o]
   (condp instance? o
     MovingSphere {:kind 2 :geom (concat (v3 (:center0 o)) [(double (:radius o))] (v3 (:center1 o))
                                         [(double (:t0 o)) (double (:t1 o))])}
     UVSphere     {:kind 1 :geom (concat (v3 (:center o)) [(double (:radius o))] (v3 (:center o)) [0.0 1.0])}
-    Sphere       {:kind 0 :geom (concat (v3 (:center o)) [(double (:radius o))] (v3 (:center o)) [0.0 1.0])}))
+    Sphere       {:kind 0 :geom (concat (v3 (:center o)) [(double (:radius o))] (v3 (:center o)) [0.0 1.0])}
+    RectXY       {:kind 3 :geom (pad9 [(:x0 o) (:y0 o) (:x1 o) (:y1 o) (:k o)])}   ; hitable.clj:269
+    RectXZ       {:kind 4 :geom (pad9 [(:x0 o) (:z0 o) (:x1 o) (:z1 o) (:k o)])}   ; hitable.clj:301
+    RectYZ       {:kind 5 :geom (pad9 [(:y0 o) (:z0 o) (:y1 o) (:z1 o) (:k o)])}   ; hitable.clj:333
+    Triangle     {:kind 6 :geom (concat (v3 (:v0 o)) (v3 (:v1 o)) (v3 (:v2 o)))})) ; hitable.clj:548
 
 (defn- camera-row [c]
   (condp instance? c
@@ -106,11 +126,17 @@
 (defn flatten-scene
   "{:camera c :world w} -> the flat arrays of include/rtmi.h (as Clojure primitive arrays)"
   [{:keys [camera world]}]
-  (let [prims     (dedup-by-identity (leaves world))
+  (let [entries   (dedup-leaves (leaves world [] 0))
+        prims     (mapv :leaf entries)
         textures  (atom {:ids (java.util.IdentityHashMap.) :rows []})
         materials (atom {:ids (java.util.IdentityHashMap.) :rows []})
         prim-mat  (mapv #(intern! materials (:material %) (partial mat-row textures)) prims)
         prows     (mapv prim-row prims)
+        ;; transform table: every distinct chain once; per primitive [first count]
+        chains    (vec (distinct (remove empty? (map :chain entries))))
+        starts    (reductions + 0 (map count chains))
+        chain-at  (zipmap chains starts)
+        xforms    (vec (mapcat identity chains))
         mrows     (:rows @materials)
         trows     (:rows @textures)
         cam       (camera-row camera)]
@@ -127,7 +153,12 @@
      :tex-param (double-array (mapcat :param trows))
      :tex-child (int-array (mapcat :child trows))
      :cam-kind  (int (:kind cam))
-     :cam       (double-array (:cam cam))}))
+     :cam       (double-array (:cam cam))
+     :prim-flip  (int-array (map :flip entries))
+     :prim-xform (int-array (mapcat (fn [e] (if (empty? (:chain e)) [0 0] [(chain-at (:chain e)) (count (:chain e))])) entries))
+     :n-xforms   (count xforms)
+     :xform-kind  (int-array (map #(int (first %)) xforms))
+     :xform-param (double-array (mapcat rest xforms))}))
 
 ;;; ---------------------------------------------------------------------------------------------
 ;;; render: replaces (dorun (cp/upmap ...)) of core.clj:100-108
@@ -147,11 +178,12 @@
         cnt  (long-array 2)]
     (check (call-int "rtmi_init" (int device) (int 0) ctx))
     (try
-      (check (call-int "rtmi_scene_create" (.getValue ctx)
+      (check (call-int "rtmi_scene_create_ex" (.getValue ctx)
                        (int (:n-prims f)) (:prim-kind f) (:prim-geom f) (:prim-mat f)
                        (int (:n-mats f)) (:mat-kind f) (:mat-tex f) (:mat-param f)
                        (int (:n-tex f)) (:tex-kind f) (:tex-param f) (:tex-child f)
-                       (:cam-kind f) (:cam f) scn))
+                       (:cam-kind f) (:cam f)
+                       (:prim-flip f) (:prim-xform f) (int (:n-xforms f)) (:xform-kind f) (:xform-param f) scn))
       (try
         (check (call-int "rtmi_render" (.getValue scn) (int nx) (int ny) (int ns) (int depth) (long seed) (int precision)
                          (int 0) (int 0) (int nx) (int ny) lin rgb cnt))

@@ -10,6 +10,7 @@ Fixtures are DATA (inputs + expected outputs):
   render_cover_n3.npz         oracle render of the cover scene n=3, 48x24x4spp (flat scene arrays included)
   render_two_spheres.npz      oracle render of make-two-spheres, 40x20x4spp
   paths_cover11_moving.npz    oracle `color` of 512 rays through the moving cover scene, with segment logs
+  render_cornell.npz          oracle render (nested records) of the classic Cornell box, 40x40x8spp, with the flattened scene
 """
 import json
 import os
@@ -73,6 +74,14 @@ def main():
     lin, q, cnt = orc.render(fs, 40, 20, 4, depth=50, seed=0x5EED0002)
     np.savez_compressed(os.path.join(HERE, "render_two_spheres.npz"), nx=40, ny=20, ns=4, depth=50, seed=np.uint64(0x5EED0002),
                         linear=lin, rgb8=q, counters=cnt, **flat_dict(fs))
+
+    # ---- section 8(f3): classic Cornell box, rendered by the oracle evaluating the NESTED records ----
+    from oracle.tree import flatten_with_tree
+    fs = flatten_with_tree(r.scene.make_cornell_box(40, 40))
+    lin, q, cnt = orc.render(fs, 40, 40, 8, depth=50, seed=0x5EED0002, nthreads=8)
+    extra = {k: np.asarray(getattr(fs, k)) for k in ("prim_flip", "prim_xform", "xform_kind", "xform_param")}
+    np.savez_compressed(os.path.join(HERE, "render_cornell.npz"), nx=40, ny=40, ns=8, depth=50, seed=np.uint64(0x5EED0002),
+                        linear=lin, rgb8=q, counters=cnt, **flat_dict(fs), **extra)
 
     # ---- oracle paths with segment logs ----
     sc = r.scene.make_random_scene(200, 100, 11, True)

@@ -498,6 +498,19 @@ def test_f3_scenes_match_nested_oracle(oracle):
         ctx.close()
 
 
+def test_f3_cornell_golden_fixture():
+    z = np.load(os.path.join(GOLD, "render_cornell.npz"))
+    f = fl.FlatScene()
+    for k in ("prim_kind", "prim_geom", "prim_mat", "mat_kind", "mat_tex", "mat_param", "tex_kind", "tex_param", "tex_child", "cam",
+              "prim_flip", "prim_xform", "xform_kind", "xform_param"):
+        setattr(f, k, z[k])
+    f.cam_kind = int(z["cam_kind"])
+    ds = core.DeviceScene(f)
+    lin, q, cnt = ds.render(int(z["nx"]), int(z["ny"]), int(z["ns"]), int(z["depth"]), int(z["seed"]))
+    ds.close()
+    assert rms(lin, z["linear"]) < 1e-13 and np.array_equal(cnt, z["counters"]) and np.abs(q.astype(int) - z["rgb8"].astype(int)).max() <= 1
+
+
 def test_f3_cornell_full_size_bvh_equals_flat():
     nx, ny, ns = 400, 400, 16
     ctx = core.Context(0)

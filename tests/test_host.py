@@ -133,6 +133,17 @@ def test_golden_renders(oracle, name):
     assert np.array_equal(lin, z["linear"]) and np.array_equal(q, z["rgb8"]) and np.array_equal(cnt, z["counters"])
 
 
+def test_golden_cornell(oracle):
+    """the committed Cornell fixture is reproduced by the nested oracle, and the flattener still produces the stored arrays"""
+    from oracle.tree import flatten_with_tree
+    z = np.load(os.path.join(GOLD, "render_cornell.npz"))
+    f = flatten_with_tree(r.scene.make_cornell_box(40, 40))
+    for k in ("prim_kind", "prim_geom", "prim_mat", "prim_flip", "prim_xform", "xform_kind", "xform_param", "cam"):
+        assert np.array_equal(getattr(f, k), z[k]), k
+    lin, q, cnt = oracle.render(f, 40, 40, 8, 50, int(z["seed"]), nthreads=4)
+    assert np.array_equal(lin, z["linear"]) and np.array_equal(q, z["rgb8"]) and np.array_equal(cnt, z["counters"])
+
+
 def test_golden_scene_generator_is_stable():
     z = np.load(os.path.join(GOLD, "render_cover_n3.npz"))
     f = fl.flatten(r.scene.make_random_scene(48, 24, 3, False))
