@@ -60,7 +60,11 @@ enum { RTMI_PRIM_SPHERE = 0, RTMI_PRIM_UVSPHERE = 1, RTMI_PRIM_MOVING = 2,
        RTMI_PRIM_RECT_XY = 3, RTMI_PRIM_RECT_XZ = 4, RTMI_PRIM_RECT_YZ = 5, RTMI_PRIM_TRIANGLE = 6 };
 enum { RTMI_XFORM_TRANSLATE = 0, RTMI_XFORM_ROTATE_Y = 1 };
 enum { RTMI_MAT_LAMBERTIAN = 0, RTMI_MAT_METAL = 1, RTMI_MAT_DIELECTRIC = 2, RTMI_MAT_DIFFUSE_LIGHT = 3 };
-enum { RTMI_TEX_CONSTANT = 0, RTMI_TEX_UVGRADIENT = 1, RTMI_TEX_CHECKER = 2 };
+enum { RTMI_TEX_CONSTANT = 0, RTMI_TEX_UVGRADIENT = 1, RTMI_TEX_CHECKER = 2,
+       /* section 8(f4), texture.clj:60-138: PerlinNoise (tex_param = scale), PerlinTurbulence / Marble (scale, depth),
+        * FlipTextureU / FlipTextureV (tex_child[0] = wrapped texture), ImageMap (tex_param[0] = image index) */
+       RTMI_TEX_PERLIN_NOISE = 3, RTMI_TEX_PERLIN_TURB = 4, RTMI_TEX_MARBLE = 5, RTMI_TEX_FLIP_U = 6, RTMI_TEX_FLIP_V = 7,
+       RTMI_TEX_IMAGE = 8 };
 enum { RTMI_CAM_PINHOLE = 0, RTMI_CAM_THINLENS = 1 };
 enum { RTMI_F64 = 0, RTMI_F32 = 1 };             /* arithmetic the kernels compute in */
 enum { RTMI_ACCEL_FLAT = 0, RTMI_ACCEL_BVH = 1 }; /* Hitlist scan (hitable.clj:15-26) | bvh-node descent (hitable.clj:97-123) */
@@ -113,6 +117,13 @@ int rtmi_scene_create_ex(rtmi_ctx *ctx,
                          int32_t cam_kind, const double *cam,
                          const int32_t *prim_flip, const int32_t *prim_xform,
                          int32_t n_xforms, const int32_t *xform_kind, const double *xform_param, rtmi_scene **out_scene);
+/* The namespace-level tables of perlin.clj:6-17 as scene data (the reference fills them from the unseeded global RNG when
+ * the namespace loads): vectors[256*3] = random-vectors (unit vectors), perm[3*256] = perm-x, perm-y, perm-z (each a
+ * permutation of 0..255).  Required before rendering a scene that holds a Perlin texture. */
+int rtmi_scene_set_perlin(rtmi_scene *scene, const double *vectors, const int32_t *perm);
+/* The pixels ImageMap (texture.clj:126-133) samples: n images, wh[2*i] = width, height of image i, rgb = the images'
+ * rows (top row first, RGB bytes) concatenated.  Replaces imagez load-image / get-pixel (texture.clj:76,138). */
+int rtmi_scene_set_images(rtmi_scene *scene, int32_t n_images, const int32_t *wh, const uint8_t *rgb);
 int rtmi_scene_destroy(rtmi_scene *scene);
 
 /* ---- the hot path --------------------------------------------------------------------------- */

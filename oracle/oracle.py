@@ -34,6 +34,8 @@ class _Scene(C.Structure):
         ("cam_kind", C.c_int32), ("cam", C.c_void_p),
         ("n_nodes", C.c_int32), ("node_kind", C.c_void_p), ("node_a", C.c_void_p), ("node_d", C.c_void_p),
         ("node_prim", C.c_void_p), ("node_children", C.c_void_p), ("root", C.c_int32),
+        ("perlin_vec", C.c_void_p), ("perlin_perm", C.c_void_p), ("n_images", C.c_int32), ("image_wh", C.c_void_p),
+        ("image_off", C.c_void_p), ("image_rgb", C.c_void_p),
     ]
 
 
@@ -101,6 +103,19 @@ class Oracle:
             for k, v in tk.items():
                 setattr(s, k, v.ctypes.data)
             keep.update(tk)
+        if getattr(fs, "perlin_vectors", None) is not None:
+            keep["perlin_vec"] = _f64(fs.perlin_vectors)
+            keep["perlin_perm"] = _i32(fs.perlin_perm)
+            s.perlin_vec, s.perlin_perm = keep["perlin_vec"].ctypes.data, keep["perlin_perm"].ctypes.data
+        images = getattr(fs, "images", None) or []
+        if images:
+            imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+            keep["image_wh"] = _i32([[im.shape[1], im.shape[0]] for im in imgs])
+            sizes = [im.size for im in imgs]
+            keep["image_off"] = np.ascontiguousarray(np.concatenate([[0], np.cumsum(sizes)[:-1]]), np.int64)
+            keep["image_rgb"] = np.ascontiguousarray(np.concatenate([im.reshape(-1) for im in imgs]), np.uint8)
+            s.n_images = len(imgs)
+            s.image_wh, s.image_off, s.image_rgb = (keep[k].ctypes.data for k in ("image_wh", "image_off", "image_rgb"))
         s._keep = keep
         return s
 

@@ -67,7 +67,8 @@ typedef RTO_REAL real;
 /* ---- flat scene description (same arrays the product's C-ABI takes; include/rtmi.h) ---- */
 enum { PRIM_SPHERE = 0, PRIM_UVSPHERE = 1, PRIM_MOVING = 2 };
 enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_DIFFUSE_LIGHT = 3 };
-enum { TEX_CONSTANT = 0, TEX_UVGRADIENT = 1, TEX_CHECKER = 2 };
+enum { TEX_CONSTANT = 0, TEX_UVGRADIENT = 1, TEX_CHECKER = 2,
+       TEX_PERLIN_NOISE = 3, TEX_PERLIN_TURB = 4, TEX_MARBLE = 5, TEX_FLIP_U = 6, TEX_FLIP_V = 7, TEX_IMAGE = 8 };
 enum { CAM_PINHOLE = 0, CAM_THINLENS = 1 };
 #define PRIM_STRIDE 9 /* c0xyz, radius, c1xyz, t0, t1 */
 #define TEX_STRIDE 12 /* constant: rgb; gradient: co cu cv cuv; checker: scale */
@@ -97,6 +98,13 @@ typedef struct {
     const int32_t *node_prim;
     const int32_t *node_children; /* Hitlist items */
     int32_t root;
+    /* texture.clj:60-138 + perlin.clj: the namespace-level tables (perlin.clj:6-17; SEEDED here) and ImageMap pixels */
+    const double *perlin_vec;   /* [256][3] random-vectors */
+    const int32_t *perlin_perm; /* [3][256] perm-x, perm-y, perm-z */
+    int32_t n_images;
+    const int32_t *image_wh;    /* [n][2] */
+    const int64_t *image_off;   /* [n] byte offset into image_rgb */
+    const uint8_t *image_rgb;   /* rows top-down, RGB */
 } rto_scene;
 enum { N_SPHERE = 0, N_UVSPHERE = 1, N_MOVING = 2, N_RECT_XY = 3, N_RECT_XZ = 4, N_RECT_YZ = 5, N_TRIANGLE = 6,
        N_FLIP = 7, N_TRANSLATE = 8, N_ROTATE_Y = 9, N_HITLIST = 10, N_BOX = 11, N_BVH = 12 };
@@ -177,7 +185,42 @@ static v3 rand_in_unit_sphere(rng_t *g) {
 /* ---- scene accessors ---- */
 static inline v3 ld3(const double *p) { return V((real)p[0], (real)p[1], (real)p[2]); }
 
-/* ---- texture.clj:14-55 ---- */
+/* ---- perlin.clj:19-64 ---- */
+static real perlin_noise(const rto_scene *sc, v3 p) {
+    /* noise (45-50): ijk = (int (Math/floor p)), uvw = p - ijk */
+    const real fi = (real)floor((double)p.x), fj = (real)floor((double)p.y), fk = (real)floor((double)p.z);
+    const int i = (int)fi, j = (int)fj, k = (int)fk;
+    const real u = p.x - fi, v = p.y - fj, w = p.z - fk;
+    /* perlin-interp (31-43): hermite weights u*u*(3 - 2u) */
+    const real uu = (u * u) * ((real)3.0 - (real)2.0 * u), vv = (v * v) * ((real)3.0 - (real)2.0 * v), ww = (w * w) * ((real)3.0 - (real)2.0 * w);
+    real acc = 0;
+    for (int di = 0; di < 2; ++di)
+        for (int dj = 0; dj < 2; ++dj)
+            for (int dk = 0; dk < 2; ++dk) {
+                /* perlin-coefficients (19-29) */
+                const int idx = sc->perlin_perm[(i + di) & 255] ^ sc->perlin_perm[256 + ((j + dj) & 255)] ^ sc->perlin_perm[512 + ((k + dk) & 255)];
+                const v3 c = ld3(sc->perlin_vec + (size_t)idx * 3);
+                const v3 wv = V(u - (real)di, v - (real)dj, w - (real)dk);
+                const real A = (real)di * uu + ((real)1.0 - (real)di) * ((real)1.0 - uu);
+                const real B = (real)dj * vv + ((real)1.0 - (real)dj) * ((real)1.0 - vv);
+                const real C = (real)dk * ww + ((real)1.0 - (real)dk) * ((real)1.0 - ww);
+                const real term = ((A * B) * C) * vdot(wv, c);
+                acc = (di | dj | dk) ? acc + term : term; /* (reduce + ...) */
+            }
+    return acc;
+}
+static real perlin_turbulence(const rto_scene *sc, v3 p, int depth) { /* perlin.clj:52-64 */
+    real acc = 0, w = (real)1.0;
+    v3 pt = p;
+    for (int i = 0; i < depth; ++i) {
+        acc = acc + w * perlin_noise(sc, pt);
+        pt = vscale(pt, (real)2.0);
+        w = w / (real)2.0;
+    }
+    return acc < 0 ? -acc : acc;
+}
+
+/* ---- texture.clj:14-138 ---- */
 static v3 tex_sample(const rto_scene *sc, int32_t t, real u, real v, v3 p) {
     for (int guard = 0; guard <= sc->n_tex; ++guard) {
         const double *tp = sc->tex_param + (size_t)t * TEX_STRIDE;
@@ -195,6 +238,29 @@ static v3 tex_sample(const rto_scene *sc, int32_t t, real u, real v, v3 p) {
             real sines = (R_SIN(scale * p.x) * R_SIN(scale * p.y)) * R_SIN(scale * p.z);
             t = (sines < (real)0) ? sc->tex_child[2 * t] : sc->tex_child[2 * t + 1];
             break;
+        }
+        case TEX_PERLIN_NOISE: { /* texture.clj:60-64: (1,1,1) * 0.5 * (inc (noise (mul scale p))) */
+            real c = (real)0.5 * (perlin_noise(sc, vscale(p, (real)tp[0])) + (real)1.0);
+            return V(c, c, c);
+        }
+        case TEX_PERLIN_TURB: { /* texture.clj:74-78 */
+            real c = (real)0.5 * (perlin_turbulence(sc, vscale(p, (real)tp[0]), (int)tp[1]) + (real)1.0);
+            return V(c, c, c);
+        }
+        case TEX_MARBLE: { /* texture.clj:88-93: 0.5 * (inc (sin (+ (* scale pz) (* 10.0 (turbulence p depth))))) */
+            real c = (real)0.5 * (R_SIN((real)tp[0] * p.z + (real)10.0 * perlin_turbulence(sc, p, (int)tp[1])) + (real)1.0);
+            return V(c, c, c);
+        }
+        case TEX_FLIP_U: u = (real)1.0 - u; t = sc->tex_child[2 * t]; break; /* texture.clj:103-106 */
+        case TEX_FLIP_V: v = (real)1.0 - v; t = sc->tex_child[2 * t]; break; /* texture.clj:113-116 */
+        case TEX_IMAGE: { /* texture.clj:126-133: i = (int (* u width)), j = (int (* v height)); rgb / 255.0.
+                             (u = 1.0 indexes one past the row in the reference and throws; clamped here) */
+            const int im = (int)tp[0];
+            const int w = sc->image_wh[2 * im], hgt = sc->image_wh[2 * im + 1];
+            int i = (int)(u * (real)w), j = (int)(v * (real)hgt);
+            i = i < 0 ? 0 : (i >= w ? w - 1 : i); j = j < 0 ? 0 : (j >= hgt ? hgt - 1 : j);
+            const uint8_t *px = sc->image_rgb + sc->image_off[im] + ((size_t)j * w + i) * 3;
+            return V((real)px[0] / (real)255.0, (real)px[1] / (real)255.0, (real)px[2] / (real)255.0);
         }
         default:
             return V(0, 0, 0);

@@ -96,6 +96,16 @@ class DeviceScene:
             len(keep[6]), ptr(keep[6]), ptr(keep[7]), ptr(keep[8]), int(f.cam_kind), ptr(keep[9]),
             ptr(flip), ptr(xform), len(xk), ptr(xk), ptr(xp), C.byref(h)))
         self.handle = h
+        if getattr(f, "perlin_vectors", None) is not None:  # perlin.clj:6-17 tables (seeded)
+            vec = np.ascontiguousarray(f.perlin_vectors, np.float64)
+            perm = np.ascontiguousarray(f.perlin_perm, np.int32)
+            check(_ffi.lib().rtmi_scene_set_perlin(h, ptr(vec), ptr(perm)))
+        images = getattr(f, "images", None) or []
+        if images:  # ImageMap pixels (texture.clj:126-133)
+            imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+            wh = np.ascontiguousarray([[im.shape[1], im.shape[0]] for im in imgs], np.int32)
+            rgb = np.ascontiguousarray(np.concatenate([im.reshape(-1) for im in imgs]), np.uint8)
+            check(_ffi.lib().rtmi_scene_set_images(h, len(imgs), ptr(wh), ptr(rgb)))
 
     def close(self):
         if self.handle:

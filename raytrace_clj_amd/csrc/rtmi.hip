@@ -364,18 +364,18 @@ template <typename R> __global__ void probe_camera_kernel(ScenePtr scp, int n, c
     o[0] = P.ox; o[1] = P.oy; o[2] = P.oz; o[3] = P.dx; o[4] = P.dy; o[5] = P.dz; o[6] = P.time; o[7] = (double)P.ctr;
 }
 
-template <typename R> __global__ void probe_texture_kernel(ScenePtr scp, int tex, int n, const double *uvp, double *out) {
+template <typename R, bool F4 = false> __global__ void probe_texture_kernel(ScenePtr scp, int tex, int n, const double *uvp, double *out) {
     SceneRef sc = *scp;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const double *q = uvp + (size_t)k * 5;
     R r, g, b;
-    tex_sample<R>(sc, tex, (R)q[0], (R)q[1], (R)q[2], (R)q[3], (R)q[4], r, g, b);
+    tex_sample<R, F4>(sc, tex, (R)q[0], (R)q[1], (R)q[2], (R)q[3], (R)q[4], r, g, b);
     out[3 * k] = r; out[3 * k + 1] = g; out[3 * k + 2] = b;
 }
 
 // Shader.scatter (shader.clj) on an explicit hit record {p, normal, u, v}: the same scatter_emit the render kernel runs.
-template <typename R>
+template <typename R, bool F4 = false>
 __global__ void probe_scatter_kernel(ScenePtr scp, int mat, int n, const double *rays, const double *hits, const u64 *keys, double *out) {
     SceneRef sc = *scp;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -388,7 +388,7 @@ __global__ void probe_scatter_kernel(ScenePtr scp, int mat, int n, const double 
     h.t = R(0); h.px = (R)hq[0]; h.py = (R)hq[1]; h.pz = (R)hq[2]; h.nx = (R)hq[3]; h.ny = (R)hq[4]; h.nz = (R)hq[5];
     h.u = (R)hq[6]; h.v = (R)hq[7]; h.orig = -1; h.kind = RTMI_PRIM_SPHERE; h.mat = mat;
     R att[3] = {R(0), R(0), R(0)};
-    const bool scat = scatter_emit<R>(sc, P, h, att);
+    const bool scat = scatter_emit<R, F4>(sc, P, h, att);
     double *o = out + (size_t)k * 9;
     o[0] = scat ? 1.0 : 0.0;
     o[1] = scat ? P.dx : 0; o[2] = scat ? P.dy : 0; o[3] = scat ? P.dz : 0;
@@ -484,6 +484,9 @@ struct rtmi_scene {
     ScenePtr d_dev = nullptr;   // the descriptor in HBM (what the kernels read)
     std::vector<void *> allocs;
     int n_prims = 0, n_mats = 0, n_tex = 0;
+    bool uses_perlin = false; // a Perlin texture is present: rtmi_scene_set_perlin must have been called before rendering
+    int max_image = -1;       // highest ImageMap index: rtmi_scene_set_images must cover it
+    bool have_perlin = false;
 };
 
 namespace {
@@ -806,7 +809,9 @@ int check_render_args(rtmi_scene *s, int nx, int ny, int ns, int depth, int prec
     if (nx <= 0 || ny <= 0 || ns <= 0 || depth < 0) return fail(RTMI_E_ARG, "nx, ny, ns must be > 0 and depth >= 0 (got %d %d %d %d)", nx, ny, ns, depth);
     if ((long long)nx * ny > (1ll << 30)) return fail(RTMI_E_ARG, "frame too large");
     if (precision != RTMI_F64 && precision != RTMI_F32) return fail(RTMI_E_ARG, "precision must be RTMI_F64 or RTMI_F32");
-    if (precision == RTMI_F32 && s->dev.has_ext) return fail(RTMI_E_UNSUPPORTED, "rectangles / triangles / instances are rendered by the FP64 kernels only");
+    if (precision == RTMI_F32 && s->dev.has_ext) return fail(RTMI_E_UNSUPPORTED, "rectangles / triangles / instances / procedural textures are rendered by the FP64 kernels only");
+    if (s->uses_perlin && !s->have_perlin) return fail(RTMI_E_STATE, "the scene holds a Perlin texture: call rtmi_scene_set_perlin first");
+    if (s->max_image >= s->dev.n_images) return fail(RTMI_E_STATE, "the scene holds an ImageMap with index %d: call rtmi_scene_set_images first", s->max_image);
     return RTMI_OK;
 }
 
@@ -909,7 +914,11 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     if (cam_kind != RTMI_CAM_PINHOLE && cam_kind != RTMI_CAM_THINLENS) return fail(RTMI_E_UNSUPPORTED, "camera kind %d unsupported on GPU path", cam_kind);
     // validate: this is where "unknown record type -> explicit unsupported error" surfaces
     for (int t = 0; t < n_tex; ++t) {
-        if (tex_kind[t] < RTMI_TEX_CONSTANT || tex_kind[t] > RTMI_TEX_CHECKER) return fail(RTMI_E_UNSUPPORTED, "texture %d: kind %d unsupported on GPU path", t, tex_kind[t]);
+        if (tex_kind[t] < RTMI_TEX_CONSTANT || tex_kind[t] > RTMI_TEX_IMAGE) return fail(RTMI_E_UNSUPPORTED, "texture %d: kind %d unsupported on GPU path", t, tex_kind[t]);
+        if (tex_kind[t] == RTMI_TEX_FLIP_U || tex_kind[t] == RTMI_TEX_FLIP_V) {
+            const int ch = tex_child[2 * t];
+            if (ch < 0 || ch >= n_tex || ch == t) return fail(RTMI_E_ARG, "texture %d: wrapped texture %d invalid", t, ch);
+        }
         if (tex_kind[t] == RTMI_TEX_CHECKER)
             for (int k = 0; k < 2; ++k) {
                 const int ch = tex_child[2 * t + k];
@@ -922,7 +931,17 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     }
     std::vector<double> stat_geom, mov_geom, stat4_d;
     std::vector<float> stat4_f;
-    bool has_ext = false;
+    bool has_ext = false, uses_perlin = false;
+    int max_image = -1;
+    for (int t = 0; t < n_tex; ++t) {
+        if (tex_kind[t] > RTMI_TEX_CHECKER) has_ext = true; // section 8(f4) textures live in the EXT kernels only
+        if (tex_kind[t] >= RTMI_TEX_PERLIN_NOISE && tex_kind[t] <= RTMI_TEX_MARBLE) uses_perlin = true;
+        if (tex_kind[t] == RTMI_TEX_IMAGE) {
+            const double im = tex_param[(size_t)t * RTMI_TEX_STRIDE];
+            if (!(im >= 0 && im < 1e6 && im == std::floor(im))) return fail(RTMI_E_ARG, "texture %d: image index invalid", t);
+            max_image = std::max(max_image, (int)im);
+        }
+    }
     std::vector<int> stat_orig, mov_orig, pk((size_t)n_prims), pm((size_t)n_prims);
     for (int i = 0; i < n_prims; ++i) {
         const int kind = prim_kind[i];
@@ -951,6 +970,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     rtmi_scene *s = new (std::nothrow) rtmi_scene();
     if (!s) return fail(RTMI_E_NOMEM, "out of host memory");
     s->ctx = c; s->n_prims = n_prims; s->n_mats = n_mats; s->n_tex = n_tex;
+    s->uses_perlin = uses_perlin; s->max_image = max_image;
     DevScene &d = s->dev;
     d.n_static = (int)stat_orig.size(); d.n_moving = (int)mov_orig.size(); d.n_tex = n_tex; d.cam_kind = cam_kind;
     std::memcpy(d.cam, cam, 24 * sizeof(double));
@@ -1096,6 +1116,57 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     if (rc) { rtmi_scene_destroy(s); return rc; }
     *out_scene = s;
     return RTMI_OK;
+}
+
+namespace {
+int reupload_descriptor(rtmi_scene *s) {
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    HIP_TRY(hipMemcpy((void *)s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice));
+    return RTMI_OK;
+}
+} // namespace
+
+RTMI_EXPORT int rtmi_scene_set_perlin(rtmi_scene *s, const double *vectors, const int32_t *perm) {
+    if (!scene_ok(s)) return fail(RTMI_E_STATE, "invalid scene handle");
+    if (!vectors || !perm) return fail(RTMI_E_ARG, "NULL array");
+    for (int a = 0; a < 3; ++a) { // each must be a permutation of 0..255 (perlin.clj:10-17)
+        bool seen[256] = {false};
+        for (int k = 0; k < 256; ++k) {
+            const int v = perm[a * 256 + k];
+            if (v < 0 || v > 255 || seen[v]) return fail(RTMI_E_ARG, "perm-%c is not a permutation of 0..255", "xyz"[a]);
+            seen[v] = true;
+        }
+    }
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    std::vector<double> v(vectors, vectors + 768);
+    std::vector<int> p(perm, perm + 768);
+    int rc = upload(s, v, &s->dev.perlin_vec);
+    if (!rc) rc = upload(s, p, &s->dev.perlin_perm);
+    if (rc) return rc;
+    s->have_perlin = true;
+    return reupload_descriptor(s);
+}
+
+RTMI_EXPORT int rtmi_scene_set_images(rtmi_scene *s, int32_t n_images, const int32_t *wh, const uint8_t *rgb) {
+    if (!scene_ok(s)) return fail(RTMI_E_STATE, "invalid scene handle");
+    if (n_images < 0 || (n_images > 0 && (!wh || !rgb))) return fail(RTMI_E_ARG, "bad image arguments");
+    std::vector<int> whv;
+    std::vector<long long> off;
+    long long total = 0;
+    for (int i = 0; i < n_images; ++i) {
+        if (wh[2 * i] <= 0 || wh[2 * i + 1] <= 0 || wh[2 * i] > 65536 || wh[2 * i + 1] > 65536) return fail(RTMI_E_ARG, "image %d: bad size %dx%d", i, wh[2 * i], wh[2 * i + 1]);
+        whv.push_back(wh[2 * i]); whv.push_back(wh[2 * i + 1]);
+        off.push_back(total);
+        total += (long long)wh[2 * i] * wh[2 * i + 1] * 3;
+    }
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    std::vector<unsigned char> px(rgb, rgb + total);
+    int rc = upload(s, whv, &s->dev.image_wh);
+    if (!rc) rc = upload(s, off, &s->dev.image_off);
+    if (!rc) rc = upload(s, px, &s->dev.image_rgb);
+    if (rc) return rc;
+    s->dev.n_images = n_images;
+    return reupload_descriptor(s);
 }
 
 RTMI_EXPORT int rtmi_scene_destroy(rtmi_scene *s) {
@@ -1331,7 +1402,10 @@ RTMI_EXPORT int rtmi_probe_texture(rtmi_scene *s, int32_t precision, int32_t tex
     double *d_in = (double *)tmp.up(uvp, (size_t)n * 5 * sizeof(double));
     double *d_out = (double *)tmp.alloc((size_t)n * 3 * sizeof(double));
     if (!d_in || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
-    if (precision == RTMI_F64) hipLaunchKernelGGL((probe_texture_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, tex, n, d_in, d_out);
+    if (s->dev.has_ext) {
+        if (precision != RTMI_F64) return fail(RTMI_E_UNSUPPORTED, "procedural / image textures are FP64 only");
+        hipLaunchKernelGGL((probe_texture_kernel<double, true>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, tex, n, d_in, d_out);
+    } else if (precision == RTMI_F64) hipLaunchKernelGGL((probe_texture_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, tex, n, d_in, d_out);
     else hipLaunchKernelGGL((probe_texture_kernel<float>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, tex, n, d_in, d_out);
     PROBE_EPILOGUE()
     HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
@@ -1348,7 +1422,10 @@ RTMI_EXPORT int rtmi_probe_scatter(rtmi_scene *s, int32_t precision, int32_t mat
     u64 *d_keys = (u64 *)tmp.up(keys, (size_t)n * sizeof(u64));
     double *d_out = (double *)tmp.alloc((size_t)n * 9 * sizeof(double));
     if (!d_rays || !d_hits || !d_keys || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
-    if (precision == RTMI_F64) hipLaunchKernelGGL((probe_scatter_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, mat, n, d_rays, d_hits, d_keys, d_out);
+    if (s->dev.has_ext) {
+        if (precision != RTMI_F64) return fail(RTMI_E_UNSUPPORTED, "procedural / image textures are FP64 only");
+        hipLaunchKernelGGL((probe_scatter_kernel<double, true>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, mat, n, d_rays, d_hits, d_keys, d_out);
+    } else if (precision == RTMI_F64) hipLaunchKernelGGL((probe_scatter_kernel<double>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, mat, n, d_rays, d_hits, d_keys, d_out);
     else hipLaunchKernelGGL((probe_scatter_kernel<float>), dim3(grid), dim3(kBlock), 0, c->stream, s->d_dev, mat, n, d_rays, d_hits, d_keys, d_out);
     PROBE_EPILOGUE()
     HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost));

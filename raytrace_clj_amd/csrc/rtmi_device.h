@@ -39,6 +39,13 @@ struct DevScene {
     int has_ext;             // any primitive kind > 2, any instance wrapper, any flip
     const int *ext_info;     // [n_all][4]: kind, FlipNormals parity, first xform, xform count (outermost first)
     const double *ext_xf;    // [n_xforms][4]: 0 | offset.xyz  (Translate)   or   1 | sin, cos, 0  (RotateY)
+    // section 8(f4): perlin.clj:6-17 tables (seeded scene data) and ImageMap pixels (texture.clj:126-133)
+    const double *perlin_vec; // [256][3]
+    const int *perlin_perm;   // [3][256]
+    int n_images;
+    const int *image_wh;      // [n][2]
+    const long long *image_off;
+    const unsigned char *image_rgb;
     const int *stat_orig;    // [n_static] index in the caller's Hitlist
     const double *mov_geom;  // [n_moving][9]  c0.xyz radius c1.xyz t0 t1
     const int *mov_orig;
@@ -182,8 +189,39 @@ template <> __device__ inline int sin_sign<double>(double x) {
     return (odd != (r < 0.0)) ? -1 : 1;
 }
 
-// texture.clj:14-16, 26-34, 44-50 (Texture.sample); checker children are walked iteratively
-template <typename R> __device__ inline void tex_sample(SceneRef sc, int t, R u, R v, R px, R py, R pz, R &r, R &g, R &b) {
+// perlin.clj:19-50: noise = trilinear hermite blend of the dot products with the 8 surrounding lattice vectors
+template <typename R> __device__ inline R perlin_noise(SceneRef sc, R px, R py, R pz) {
+    const R fi = (R)::floor((double)px), fj = (R)::floor((double)py), fk = (R)::floor((double)pz);
+    const int i = (int)fi, j = (int)fj, k = (int)fk;
+    const R u = px - fi, v = py - fj, w = pz - fk;
+    const R uu = (u * u) * (R(3.0) - R(2.0) * u), vv = (v * v) * (R(3.0) - R(2.0) * v), ww = (w * w) * (R(3.0) - R(2.0) * w);
+    R acc = R(0);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { // (for [di dj dk]) with dk fastest; (reduce + ...) in that order
+        const int di = c >> 2, dj = (c >> 1) & 1, dk = c & 1;
+        const int idx = sc.perlin_perm[(i + di) & 255] ^ sc.perlin_perm[256 + ((j + dj) & 255)] ^ sc.perlin_perm[512 + ((k + dk) & 255)];
+        const double *g = sc.perlin_vec + (size_t)idx * 3;
+        const R A = di ? uu : R(1.0) - uu, B = dj ? vv : R(1.0) - vv, C = dk ? ww : R(1.0) - ww; // i*uu + (1-i)*(1-uu), exactly
+        const R d = dot3(u - (R)di, v - (R)dj, w - (R)dk, (R)g[0], (R)g[1], (R)g[2]);
+        const R term = ((A * B) * C) * d;
+        acc = c ? acc + term : term;
+    }
+    return acc;
+}
+// perlin.clj:52-64
+template <typename R> __device__ inline R perlin_turbulence(SceneRef sc, R px, R py, R pz, int depth) {
+    R acc = R(0), w = R(1.0);
+    for (int i = 0; i < depth; ++i) {
+        acc = acc + w * perlin_noise<R>(sc, px, py, pz);
+        px = R(2.0) * px; py = R(2.0) * py; pz = R(2.0) * pz;
+        w = w / R(2.0);
+    }
+    return acc < R(0) ? -acc : acc;
+}
+
+// texture.clj:14-16, 26-34, 44-50 (Texture.sample); checker children are walked iteratively.
+// F4 (only in the EXT kernel instantiations): Perlin noise / turbulence / marble, FlipTextureU/V, ImageMap (texture.clj:60-138)
+template <typename R, bool F4 = false> __device__ inline void tex_sample(SceneRef sc, int t, R u, R v, R px, R py, R pz, R &r, R &g, R &b) {
     r = g = b = R(0);
     for (int guard = 0; guard <= sc.n_tex; ++guard) {
         const double *tp = sc.tex_param + (size_t)t * RTMI_TEX_STRIDE;
@@ -206,6 +244,33 @@ template <typename R> __device__ inline void tex_sample(SceneRef sc, int t, R u,
             const int sx = sin_sign<R>(scale * px), sy = sin_sign<R>(scale * py), sz = sin_sign<R>(scale * pz);
             t = (sx * sy * sz < 0) ? sc.tex_child[2 * t] : sc.tex_child[2 * t + 1];
             continue;
+        }
+        if (F4) {
+            if (kind == RTMI_TEX_PERLIN_NOISE) { // (mul (vec3 1 1 1) (* 0.5 (inc (noise (mul scale p)))))
+                const R s = (R)tp[0];
+                r = g = b = R(0.5) * (perlin_noise<R>(sc, s * px, s * py, s * pz) + R(1.0));
+                return;
+            }
+            if (kind == RTMI_TEX_PERLIN_TURB) {
+                const R s = (R)tp[0];
+                r = g = b = R(0.5) * (perlin_turbulence<R>(sc, s * px, s * py, s * pz, (int)tp[1]) + R(1.0));
+                return;
+            }
+            if (kind == RTMI_TEX_MARBLE) { // 0.5 * (inc (sin (+ (* scale pz) (* 10.0 (turbulence p depth)))))
+                r = g = b = R(0.5) * (Real<R>::sin_((R)tp[0] * pz + R(10.0) * perlin_turbulence<R>(sc, px, py, pz, (int)tp[1])) + R(1.0));
+                return;
+            }
+            if (kind == RTMI_TEX_FLIP_U) { u = R(1.0) - u; t = sc.tex_child[2 * t]; continue; }
+            if (kind == RTMI_TEX_FLIP_V) { v = R(1.0) - v; t = sc.tex_child[2 * t]; continue; }
+            if (kind == RTMI_TEX_IMAGE) { // i = (int (* u width)), j = (int (* v height)), rgb / 255.0 (clamped: u = 1.0 throws in the reference)
+                const int im = (int)tp[0];
+                const int w = sc.image_wh[2 * im], h = sc.image_wh[2 * im + 1];
+                int i = (int)(u * (R)w), j = (int)(v * (R)h);
+                i = i < 0 ? 0 : (i >= w ? w - 1 : i); j = j < 0 ? 0 : (j >= h ? h - 1 : j);
+                const unsigned char *q = sc.image_rgb + sc.image_off[im] + ((size_t)j * w + i) * 3;
+                r = (R)q[0] / R(255.0); g = (R)q[1] / R(255.0); b = (R)q[2] / R(255.0);
+                return;
+            }
         }
         return;
     }
@@ -852,7 +917,7 @@ template <> __device__ inline void resolve_any<double, true>(SceneRef sc, const 
 // Shader.scatter + Shader.emitted for the hit record, and the atten/accum update of core.clj:27-39.
 // Returns true when the path continues (the `recur` of core.clj:30) with P holding the scattered ray.
 // `att` (optional) receives the attenuation of a successful scatter.
-template <typename R> __device__ inline bool scatter_emit(SceneRef sc, Path<R> &P, const HitRec<R> &h, R *att) {
+template <typename R, bool F4 = false> __device__ inline bool scatter_emit(SceneRef sc, Path<R> &P, const HitRec<R> &h, R *att) {
     // The material switch is laid out in PHASES shared by the materials that need them (one rejection-sampler loop,
     // one |d| normalisation, one texture evaluation per trip) instead of one inlined copy per material: the lanes of a
     // wave hold different materials, so every copy would be executed serially.  Per lane the operations and the draw
@@ -915,7 +980,7 @@ template <typename R> __device__ inline bool scatter_emit(SceneRef sc, Path<R> &
     // Lambertian / Metal scatter (shader.clj:34,57)
     if (is_light || is_lamb || (is_metal && scat)) {
         R tr, tg, tb;
-        tex_sample(sc, sc.mat_tex[mat], h.u, h.v, px, py, pz, tr, tg, tb);
+        tex_sample<R, F4>(sc, sc.mat_tex[mat], h.u, h.v, px, py, pz, tr, tg, tb);
         if (is_light) { P.cr = P.cr + P.ar * tr; P.cg = P.cg + P.ag * tg; P.cb = P.cb + P.ab * tb; } // core.clj:37-39
         else { atr = tr; atg = tg; atb = tb; }
     }
@@ -934,7 +999,7 @@ __device__ inline bool shade_segment(SceneRef sc, Path<R> &P, R t, int orig, Seg
     if (orig < 0) return false; // miss: (color) returns accum, core.clj:40-41
     HitRec<R> h;
     resolve_any<R, EXT>(sc, P, t, orig, h);
-    const bool scat = scatter_emit<R>(sc, P, h, nullptr);
+    const bool scat = scatter_emit<R, EXT>(sc, P, h, nullptr);
     if (lg && lg->n < lg->max_seg) {
         double *q = lg->rec + (size_t)lg->n * RTMI_SEG_REC;
         q[0] = h.orig; q[1] = h.t; q[2] = h.px; q[3] = h.py; q[4] = h.pz; q[5] = h.nx; q[6] = h.ny; q[7] = h.nz;

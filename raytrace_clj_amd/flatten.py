@@ -19,6 +19,7 @@ PRIM_RECT_XY, PRIM_RECT_XZ, PRIM_RECT_YZ, PRIM_TRIANGLE = 3, 4, 5, 6
 XFORM_TRANSLATE, XFORM_ROTATE_Y = 0, 1
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
 TEX_CONSTANT, TEX_UVGRADIENT, TEX_CHECKER = 0, 1, 2
+TEX_PERLIN_NOISE, TEX_PERLIN_TURB, TEX_MARBLE, TEX_FLIP_U, TEX_FLIP_V, TEX_IMAGE = 3, 4, 5, 6, 7, 8
 CAM_PINHOLE, CAM_THINLENS = 0, 1
 PRIM_STRIDE, TEX_STRIDE = 9, 12
 
@@ -48,6 +49,10 @@ class FlatScene:
         self.prim_xform = np.zeros((0, 2), np.int32)   # first, count
         self.xform_kind = np.zeros(0, np.int32)
         self.xform_param = np.zeros((0, 3), np.float64)  # translate: offset.xyz | rotate-y: sin, cos, 0
+        # procedural / image textures (texture.clj:60-138): the Perlin tables (perlin.clj:6-17, seeded) and ImageMap pixels
+        self.perlin_vectors = None  # [256, 3] float64, set when a Perlin texture is present
+        self.perlin_perm = None     # [3, 256] int32
+        self.images = []            # [h, w, 3] uint8 arrays; TEX_IMAGE's first parameter indexes this list
 
     @property
     def n_prims(self):
@@ -99,7 +104,7 @@ class _Interner:
         return self.ids[k]
 
 
-def flatten(scene_or_world, camera=None):
+def flatten(scene_or_world, camera=None, perlin_seed=None):
     """flatten({"camera": c, "world": w}) or flatten(world, camera) -> FlatScene"""
     if isinstance(scene_or_world, dict):
         world, camera = scene_or_world["world"], scene_or_world["camera"]
@@ -109,6 +114,7 @@ def flatten(scene_or_world, camera=None):
     _leaves(world, leaves, set())
 
     textures, materials = _Interner(), _Interner()
+    uses, images = {"perlin": False}, []
 
     def build_tex(t):
         p = np.zeros(TEX_STRIDE)
@@ -123,6 +129,21 @@ def flatten(scene_or_world, camera=None):
             c1 = textures.get(t.tex1, build_tex)
             p[0] = t.scale
             return (TEX_CHECKER, p, (c0, c1))
+        if isinstance(t, tex.PerlinNoise):
+            uses["perlin"] = True
+            p[0] = t.scale
+            return (TEX_PERLIN_NOISE, p, (-1, -1))
+        if isinstance(t, (tex.PerlinTurbulence, tex.Marble)):
+            uses["perlin"] = True
+            p[0], p[1] = t.scale, t.depth
+            return (TEX_PERLIN_TURB if isinstance(t, tex.PerlinTurbulence) else TEX_MARBLE, p, (-1, -1))
+        if isinstance(t, (tex.FlipTextureU, tex.FlipTextureV)):
+            c0 = textures.get(t.tex, build_tex)
+            return (TEX_FLIP_U if isinstance(t, tex.FlipTextureU) else TEX_FLIP_V, p, (c0, -1))
+        if isinstance(t, tex.ImageMap):
+            p[0] = len(images)
+            images.append(t.image)
+            return (TEX_IMAGE, p, (-1, -1))
         raise UnsupportedOnGpuPath("texture %s is not supported on the GPU path" % type(t).__name__)
 
     def build_mat(m):
@@ -182,6 +203,10 @@ def flatten(scene_or_world, camera=None):
     fs.tex_param = np.array([r[1] for r in textures.rows], np.float64).reshape(-1, TEX_STRIDE)
     fs.tex_child = np.array([r[2] for r in textures.rows], np.int32).reshape(-1, 2)
 
+    fs.images = images
+    if uses["perlin"]:
+        from . import perlin
+        fs.perlin_vectors, fs.perlin_perm = perlin.make_tables(perlin.PERLIN_SEED if perlin_seed is None else perlin_seed)
     if camera is not None:
         fs.cam_kind, fs.cam = flatten_camera(camera)
     return fs

@@ -6,8 +6,10 @@ The reference draws scene randomness from the unseeded clojure.core/rand; here e
 next value of a seeded SplitMix64 stream, consumed in the reference's evaluation order (per grid cell:
 centre x, centre z, choose-mat, then the material's own draws; cells failing the :when filter still
 consume their three draws).  make_two_triangles = scene.clj:80-114 and make_cornell_box (classic) = scene.clj:230-316 use the section-8(f3) records
-(rectangles, boxes, instances, triangles).  The remaining scene functions need Perlin / image textures or ConstantMedium,
-which are outside the GPU path's scope."""
+(rectangles, boxes, instances, triangles); make_two_perlin_spheres = scene.clj:50-78, make_textured_sphere = scene.clj:116-150
+(its earth.png is not in the reference repository: a synthetic image stands in) and make_example_light = scene.clj:191-228
+use the section-8(f4) textures.  make-subsurface-sphere, the foggy Cornell box and make-final need ConstantMedium, which the
+GPU path does not implement."""
 import math
 
 import numpy as np
@@ -42,6 +44,67 @@ def make_two_spheres(nx, ny, seed=SCENE_SEED):
             hit.uv_sphere(center=vec3(0, 2, 0), radius=2,
                           material=shad.lambertian(albedo=tex.uv_gradient(co=vec3(0, 1, 0), cu=vec3(0, 1, 1),
                                                                           cv=vec3(1, 0, 1), cuv=vec3(1, 0, 0)))),
+        ], 0.0, 1.0, rng),
+    }
+
+
+def make_two_perlin_spheres(nx, ny, seed=SCENE_SEED):
+    """two perlin noise spheres -- scene.clj:50-78"""
+    rng = SplitMix64(seed)
+    turb = tex.perlin_turbulence(scale=4, depth=7)
+    return {
+        "camera": cam.thin_lens_camera(lookfrom=vec3(13, 2, 3), lookat=vec3(0, 1, 0), vup=vec3(0, 1, 0), vfov=40,
+                                       aspect=_aspect(nx, ny), aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0),
+        "world": hit.make_bvh([
+            hit.sphere(center=vec3(0, 0, 0), radius=1000, material=shad.diffuse_light(tex=tex.constant(color=0.8 * vec3(0.3, 0.5, 0.8)))),
+            hit.sphere(center=vec3(0, -1000, 0), radius=1000, material=shad.lambertian(albedo=turb)),
+            hit.sphere(center=vec3(0, 2, 0), radius=2, material=shad.lambertian(albedo=turb)),
+        ], 0.0, 1.0, rng),
+    }
+
+
+def synthetic_earth(w=256, h=128):
+    """stand-in for the reference's earth.png (scene.clj:125-126: not in the repository, *.png is git-ignored): a
+    deterministic land/ocean pattern, [h, w, 3] uint8"""
+    y, x = np.mgrid[0:h, 0:w]
+    lon, lat = x / w * 2 * np.pi, (y / h - 0.5) * np.pi
+    land = (np.sin(3 * lon) * np.cos(2 * lat) + 0.5 * np.sin(7 * lon + 1.3) * np.sin(5 * lat) + 0.3 * np.cos(11 * lon - 2 * lat)) > 0.25
+    img = np.zeros((h, w, 3), np.uint8)
+    img[...] = (20, 60, 140)
+    img[land] = (40, 130, 50)
+    img[np.abs(lat) > 1.25] = (235, 240, 245)
+    return img
+
+
+def make_textured_sphere(nx, ny, image=None, seed=SCENE_SEED):
+    """texture mapped sphere -- scene.clj:116-150 (earth.png replaced by `image`, default synthetic_earth())"""
+    rng = SplitMix64(seed)
+    checker = tex.checkerboard(tex0=tex.constant(color=vec3(0.2, 0.3, 0.1)), tex1=tex.constant(color=vec3(0.9, 0.9, 0.9)), scale=10)
+    earth = tex.flip_texture_v(tex=tex.image_map(image=synthetic_earth() if image is None else image))
+    return {
+        "camera": cam.thin_lens_camera(lookfrom=vec3(13, 2, 3), lookat=vec3(0, 1, 0), vup=vec3(0, 1, 0), vfov=15,
+                                       aspect=_aspect(nx, ny), aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0),
+        "world": hit.make_bvh([
+            hit.sphere(center=vec3(0, 0, 0), radius=1000, material=shad.diffuse_light(tex=tex.constant(color=0.8 * vec3(0.3, 0.5, 0.8)))),
+            hit.sphere(center=vec3(0, -10, 0), radius=10, material=shad.lambertian(albedo=checker)),
+            hit.uv_sphere(center=vec3(0, 1, 0), radius=1, material=shad.lambertian(albedo=earth)),
+        ], 0.0, 1.0, rng),
+    }
+
+
+def make_example_light(nx, ny, seed=SCENE_SEED):
+    """scene with rectangular area light -- scene.clj:191-228"""
+    rng = SplitMix64(seed)
+    gray = shad.lambertian(albedo=tex.constant(color=vec3(0.6, 0.6, 0.6)))
+    light = shad.diffuse_light(tex=tex.constant(color=vec3(4, 4, 4)))
+    return {
+        "camera": cam.thin_lens_camera(lookfrom=vec3(13, 2, 3), lookat=vec3(0, 1, 0), vup=vec3(0, 1, 0), vfov=40,
+                                       aspect=_aspect(nx, ny), aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0),
+        "world": hit.make_bvh([
+            hit.sphere(center=vec3(0, -1000, 0), radius=1000, material=gray),
+            hit.sphere(center=vec3(0, 2, 0), radius=2, material=gray),
+            hit.sphere(center=vec3(0, 7, 0), radius=2, material=light),
+            hit.rect_xy(x0=3, y0=1, x1=5, y1=3, k=-2, material=light),
         ], 0.0, 1.0, rng),
     }
 

@@ -498,6 +498,52 @@ def test_f3_scenes_match_nested_oracle(oracle):
         ctx.close()
 
 
+def test_f4_textures_and_scenes_match_oracle(oracle):
+    """section 8(f4): Perlin noise / turbulence / marble, FlipTextureU/V, ImageMap on the device vs the oracle"""
+    from oracle.tree import flatten_with_tree
+    T = r.texture
+    img = r.scene.synthetic_earth(64, 32)
+    texs = [T.perlin_noise(scale=1.0), T.perlin_noise(scale=4.0), T.perlin_turbulence(scale=4, depth=7), T.marble(scale=4, depth=5),
+            T.image_map(image=img), T.flip_texture_v(tex=T.image_map(image=img)),
+            T.flip_texture_u(tex=T.uv_gradient(co=vec3(1, 0, 0), cu=vec3(0, 1, 0), cv=vec3(0, 0, 1), cuv=vec3(1, 1, 1))),
+            T.checkerboard(tex0=T.marble(scale=2, depth=3), tex1=T.flip_texture_u(tex=T.image_map(image=img)), scale=3.0)]
+    world = r.hitable.hitlist(items=[r.hitable.sphere(center=vec3(0, 0, 0), radius=1.0, material=r.shader.lambertian(albedo=t)) for t in texs])
+    f = fl.flatten(world, r.camera.PinholeCamera(*(np.zeros(3),) * 4))
+    rng = np.random.default_rng(5)
+    uvp = np.concatenate([rng.random((5000, 2)), rng.normal(0, 9, (5000, 3))], axis=1)
+    uvp[:50, 2:] = np.round(uvp[:50, 2:])  # lattice points
+    uvp[50:60, 0] = 1.0; uvp[60:70, 1] = 1.0; uvp[70:80, :2] = 0.0
+    ds = core.DeviceScene(f)
+    for m in range(len(texs)):
+        t = int(f.mat_tex[m])
+        got, exp = ds.probe_texture(t, uvp), oracle.probe_texture(f, t, uvp)
+        if isinstance(texs[m], (T.Marble, T.Checkerboard)):
+            assert np.allclose(got, exp, atol=1e-14, rtol=0) or (got == exp).all(axis=1).mean() > 0.999  # sin: ocml vs glibc
+        else:
+            assert np.array_equal(got, exp), type(texs[m]).__name__
+    ds.close()
+    for name, sc in [("perlin", r.scene.make_two_perlin_spheres(64, 32)), ("earth", r.scene.make_textured_sphere(64, 32)),
+                     ("light", r.scene.make_example_light(64, 32))]:
+        ft = flatten_with_tree(sc)
+        exp_lin, exp_q, exp_cnt = oracle.render(ft, 64, 32, 8, 50, 0x5EED0002, nthreads=16)
+        ctx = core.Context(0)
+        ds = core.DeviceScene(ft, ctx=ctx)
+        for accel in (1, 0):
+            ctx.set_option("accel", accel)
+            lin, q, cnt = ds.render(64, 32, 8)
+            assert np.array_equal(cnt, exp_cnt) and rms(lin, exp_lin) < 1e-12, (name, accel)
+            assert np.abs(q.astype(int) - exp_q.astype(int)).max() <= 1
+        ds.close(); ctx.close()
+    # a Perlin scene without tables / an ImageMap without pixels is a loud error
+    f2 = fl.flatten(r.scene.make_two_perlin_spheres(16, 8))
+    f2.perlin_vectors = None
+    ds = core.DeviceScene(f2)
+    with pytest.raises(core.RtmiError) as e:
+        ds.render(16, 8, 1)
+    assert e.value.code == -5
+    ds.close()
+
+
 def test_f3_cornell_golden_fixture():
     z = np.load(os.path.join(GOLD, "render_cornell.npz"))
     f = fl.FlatScene()

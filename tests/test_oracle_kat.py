@@ -356,3 +356,75 @@ def test_f3_cornell_and_triangles_render(oracle):
     assert lin[:, :8, 1].mean() > lin[:, :8, 0].mean() and lin[:, -8:, 0].mean() > lin[:, -8:, 1].mean()
     lin2, _, _ = oracle.render(flatten_with_tree(r.scene.make_two_triangles(32, 16)), 32, 16, 8, 50, 7, nthreads=8)
     assert lin2[:, :, 2].mean() > lin2[:, :, 0].mean()  # blue-ish light dome dominates
+
+
+# ---- section 8(f4) textures (texture.clj:60-138, perlin.clj): no reference test covers them; properties + restated values ----------
+def _py_noise(vec, perm, p):
+    """independent pure-Python restatement of perlin.clj:19-50"""
+    import math
+    ijk = [math.floor(x) for x in p]
+    uvw = [p[k] - ijk[k] for k in range(3)]
+    uu, vv, ww = [(t * t) * (3 - 2 * t) for t in uvw]
+    acc = None
+    for di in (0, 1):
+        for dj in (0, 1):
+            for dk in (0, 1):
+                c = vec[perm[0][(ijk[0] + di) & 255] ^ perm[1][(ijk[1] + dj) & 255] ^ perm[2][(ijk[2] + dk) & 255]]
+                wv = (uvw[0] - di, uvw[1] - dj, uvw[2] - dk)
+                term = (((di * uu + (1.0 - di) * (1.0 - uu)) * (dj * vv + (1.0 - dj) * (1.0 - vv))) * (dk * ww + (1.0 - dk) * (1.0 - ww))) * \
+                       ((wv[0] * c[0] + wv[1] * c[1]) + wv[2] * c[2])
+                acc = term if acc is None else acc + term
+    return acc
+
+
+def test_f4_perlin_tables_and_noise(oracle):
+    from raytrace_clj_amd import perlin
+    vec, perm = perlin.make_tables()
+    assert np.allclose(np.linalg.norm(vec, axis=1), 1.0, atol=1e-15) and all(sorted(perm[a]) == list(range(256)) for a in range(3))
+    v2, p2 = perlin.make_tables()
+    assert np.array_equal(vec, v2) and np.array_equal(perm, p2) and not np.array_equal(perlin.make_tables(7)[0], vec)
+    T = r.texture
+    world = r.hitable.hitlist(items=[r.hitable.sphere(center=vec3(0, 0, 0), radius=1.0, material=r.shader.lambertian(albedo=t)) for t in
+                                     (T.perlin_noise(scale=1.0), T.perlin_turbulence(scale=4, depth=7), T.marble(scale=4, depth=5))])
+    f = fl.flatten(world, r.camera.PinholeCamera(*(np.zeros(3),) * 4))
+    assert list(f.tex_kind) == [3, 4, 5] and f.perlin_vectors.shape == (256, 3)
+    rng = np.random.default_rng(0)
+    pts = rng.normal(0, 7, (300, 3))
+    uvp = np.concatenate([np.zeros((300, 2)), pts], axis=1)
+    got = oracle.probe_texture(f, 0, uvp)
+    exp = np.array([0.5 * (_py_noise(vec, perm, p) + 1.0) for p in pts])
+    assert np.array_equal(got[:, 0], exp) and np.array_equal(got[:, 0], got[:, 2])
+    assert np.abs(2 * got[:, 0] - 1).max() < 1.0 and np.abs(2 * got[:, 0] - 1).max() > 0.2
+    # noise vanishes on the integer lattice (every weight vector with non-zero hermite weight is zero there)
+    lat = np.concatenate([np.zeros((27, 2)), np.array([[i, j, k] for i in (-2, 0, 5) for j in (-1, 0, 3) for k in (0, 1, -7)], float)], axis=1)
+    assert np.array_equal(oracle.probe_texture(f, 0, lat), np.full((27, 3), 0.5))
+    turb = oracle.probe_texture(f, 1, uvp)[:, 0]
+    assert (turb >= 0.5).all() and turb.max() < 2.0  # 0.5 * (|sum| + 1)
+    marble = oracle.probe_texture(f, 2, uvp)[:, 0]
+    assert (marble >= 0).all() and (marble <= 1).all()
+
+
+def test_f4_flip_and_image(oracle):
+    T = r.texture
+    img = np.zeros((2, 4, 3), np.uint8)
+    img[0, :, 0] = [10, 20, 30, 40]; img[1, :, 1] = [50, 60, 70, 80]
+    grad = T.uv_gradient(co=vec3(1, 0, 0), cu=vec3(0, 1, 0), cv=vec3(0, 0, 1), cuv=vec3(1, 1, 1))
+    texs = [T.image_map(image=img), T.flip_texture_v(tex=T.image_map(image=img)), T.flip_texture_u(tex=grad), grad,
+            T.flip_texture_u(tex=T.flip_texture_v(tex=T.image_map(image=img)))]
+    world = r.hitable.hitlist(items=[r.hitable.sphere(center=vec3(0, 0, 0), radius=1.0, material=r.shader.lambertian(albedo=t)) for t in texs])
+    f = fl.flatten(world, r.camera.PinholeCamera(*(np.zeros(3),) * 4))
+    def sample(mat, u, v):
+        return oracle.probe_texture(f, int(f.mat_tex[mat]), [u, v, 0, 0, 0])[0]
+    assert np.allclose(sample(0, 0.30, 0.10), (20 / 255.0, 0, 0)) and np.allclose(sample(0, 0.99, 0.75), (0, 80 / 255.0, 0))
+    assert np.allclose(sample(1, 0.30, 0.90), (20 / 255.0, 0, 0))          # FlipTextureV: v -> 1 - v
+    assert np.allclose(sample(4, 0.70, 0.90), (20 / 255.0, 0, 0))          # FlipTextureU(FlipTextureV(image))
+    assert np.allclose(sample(2, 0.25, 0.6), sample(3, 0.75, 0.6))         # FlipTextureU: u -> 1 - u
+    assert np.allclose(sample(0, 1.0, 1.0), (0, 80 / 255.0, 0))            # u = 1.0: clamped (the reference indexes out of bounds)
+
+
+def test_f4_scenes_render(oracle):
+    from oracle.tree import flatten_with_tree
+    for sc, (nx, ny) in [(r.scene.make_two_perlin_spheres(32, 16), (32, 16)), (r.scene.make_textured_sphere(32, 16), (32, 16)),
+                         (r.scene.make_example_light(32, 16), (32, 16))]:
+        lin, q, cnt = oracle.render(flatten_with_tree(sc), nx, ny, 4, 50, 3, nthreads=8)
+        assert np.isfinite(lin).all() and lin.mean() > 0.05 and cnt[1] == nx * ny
