@@ -57,9 +57,15 @@ extern "C" {
 
 enum { RTMI_PRIM_SPHERE = 0, RTMI_PRIM_UVSPHERE = 1, RTMI_PRIM_MOVING = 2,
        /* section 8(f3), via rtmi_scene_create_ex: */
-       RTMI_PRIM_RECT_XY = 3, RTMI_PRIM_RECT_XZ = 4, RTMI_PRIM_RECT_YZ = 5, RTMI_PRIM_TRIANGLE = 6 };
+       RTMI_PRIM_RECT_XY = 3, RTMI_PRIM_RECT_XZ = 4, RTMI_PRIM_RECT_YZ = 5, RTMI_PRIM_TRIANGLE = 6,
+       /* ConstantMedium (hitable.clj:516): prim_geom = density, first boundary primitive, boundary primitive count; prim_mat =
+        * its phase function (RTMI_MAT_ISOTROPIC).  The primitives of a medium's boundary come AFTER all world primitives and
+        * carry RTMI_PRIM_BOUNDARY in their kind: they exist only for the medium (a record that is both in the world and a
+        * boundary, scene.clj:434,466-469, is listed twice). */
+       RTMI_PRIM_MEDIUM = 7, RTMI_PRIM_BOUNDARY = 16 };
 enum { RTMI_XFORM_TRANSLATE = 0, RTMI_XFORM_ROTATE_Y = 1 };
-enum { RTMI_MAT_LAMBERTIAN = 0, RTMI_MAT_METAL = 1, RTMI_MAT_DIELECTRIC = 2, RTMI_MAT_DIFFUSE_LIGHT = 3 };
+enum { RTMI_MAT_LAMBERTIAN = 0, RTMI_MAT_METAL = 1, RTMI_MAT_DIELECTRIC = 2, RTMI_MAT_DIFFUSE_LIGHT = 3,
+       RTMI_MAT_ISOTROPIC = 4 /* shader.clj:129, only as a ConstantMedium's phase function */ };
 enum { RTMI_TEX_CONSTANT = 0, RTMI_TEX_UVGRADIENT = 1, RTMI_TEX_CHECKER = 2,
        /* section 8(f4), texture.clj:60-138: PerlinNoise (tex_param = scale), PerlinTurbulence / Marble (scale, depth),
         * FlipTextureU / FlipTextureV (tex_child[0] = wrapped texture), ImageMap (tex_param[0] = image index) */
@@ -108,8 +114,10 @@ int rtmi_scene_create(rtmi_ctx *ctx,
  *   prim_xform[i*2..] first index and count of primitive i's Translate / RotateY wrappers (hitable.clj:391, 410) in the
  *                     xform table, OUTERMOST FIRST;  xform_kind[k] = RTMI_XFORM_*;
  *   xform_param[k*3..] Translate: offset.xyz | RotateY: sin-theta, cos-theta, 0 (the record's fields, hitable.clj:410).
- * Box (hitable.clj:491) flattens to its six rectangles.  ConstantMedium is not supported.  Scenes that use any of this are
- * rendered by the FP64 kernels only (RTMI_F32 -> RTMI_E_UNSUPPORTED). */
+ * Box (hitable.clj:491) flattens to its six rectangles.  ConstantMedium (hitable.clj:516-541) draws its random number inside
+ * hit?: media are evaluated in primitive-index order with the un-narrowed (t-min, t-max) of the reference's bvh-node descent,
+ * so a world must not enclose a medium in a Hitlist (no scene of scene.clj does); at most 16 media per scene.  Scenes that use
+ * any of this are rendered by the FP64 kernels only (RTMI_F32 -> RTMI_E_UNSUPPORTED). */
 int rtmi_scene_create_ex(rtmi_ctx *ctx,
                          int32_t n_prims, const int32_t *prim_kind, const double *prim_geom, const int32_t *prim_mat,
                          int32_t n_mats, const int32_t *mat_kind, const int32_t *mat_tex, const double *mat_param,
@@ -124,6 +132,11 @@ int rtmi_scene_set_perlin(rtmi_scene *scene, const double *vectors, const int32_
 /* The pixels ImageMap (texture.clj:126-133) samples: n images, wh[2*i] = width, height of image i, rgb = the images'
  * rows (top row first, RGB bytes) concatenated.  Replaces imagez load-image / get-pixel (texture.clj:76,138). */
 int rtmi_scene_set_images(rtmi_scene *scene, int32_t n_images, const int32_t *wh, const uint8_t *rgb);
+/* The order in which, and how often, the reference's descent calls hit? of the scene's ConstantMedium primitives per ray:
+ * calls[k] = index of a RTMI_PRIM_MEDIUM primitive, n_calls <= 32.  Default: every medium once, ascending index.  (make-bvh
+ * stores a lone item as bvh-node(L, L), hitable.clj:113-114, and bvh-node.hit? evaluates both children: a medium there is
+ * asked twice, draws two random numbers and the nearer scattering point wins.) */
+int rtmi_scene_set_media_calls(rtmi_scene *scene, int32_t n_calls, const int32_t *calls);
 int rtmi_scene_destroy(rtmi_scene *scene);
 
 /* ---- the hot path --------------------------------------------------------------------------- */

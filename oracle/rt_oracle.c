@@ -66,7 +66,7 @@ typedef RTO_REAL real;
 
 /* ---- flat scene description (same arrays the product's C-ABI takes; include/rtmi.h) ---- */
 enum { PRIM_SPHERE = 0, PRIM_UVSPHERE = 1, PRIM_MOVING = 2 };
-enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_DIFFUSE_LIGHT = 3 };
+enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_DIFFUSE_LIGHT = 3, MAT_ISOTROPIC = 4 };
 enum { TEX_CONSTANT = 0, TEX_UVGRADIENT = 1, TEX_CHECKER = 2,
        TEX_PERLIN_NOISE = 3, TEX_PERLIN_TURB = 4, TEX_MARBLE = 5, TEX_FLIP_U = 6, TEX_FLIP_V = 7, TEX_IMAGE = 8 };
 enum { CAM_PINHOLE = 0, CAM_THINLENS = 1 };
@@ -107,7 +107,7 @@ typedef struct {
     const uint8_t *image_rgb;   /* rows top-down, RGB */
 } rto_scene;
 enum { N_SPHERE = 0, N_UVSPHERE = 1, N_MOVING = 2, N_RECT_XY = 3, N_RECT_XZ = 4, N_RECT_YZ = 5, N_TRIANGLE = 6,
-       N_FLIP = 7, N_TRANSLATE = 8, N_ROTATE_Y = 9, N_HITLIST = 10, N_BOX = 11, N_BVH = 12 };
+       N_FLIP = 7, N_TRANSLATE = 8, N_ROTATE_Y = 9, N_HITLIST = 10, N_BOX = 11, N_BVH = 12, N_MEDIUM = 13 };
 
 typedef struct { real x, y, z; } v3;
 typedef struct { v3 o, d; real time; } ray_t;
@@ -340,7 +340,7 @@ static int sphere_like_hit(v3 center0, real radius, int kind, const double *g, c
     return 0;
 }
 
-static int node_hit(const rto_scene *sc, int n, const ray_t *r, real tmin, real tmax, hit_t *h) {
+static int node_hit(const rto_scene *sc, int n, const ray_t *r, real tmin, real tmax, hit_t *h, rng_t *rng) {
     const int kind = sc->node_kind[n];
     const int32_t *a = sc->node_a + (size_t)n * 3;
     const double *g = sc->node_d + (size_t)n * 12;
@@ -384,13 +384,13 @@ static int node_hit(const rto_scene *sc, int n, const ray_t *r, real tmin, real 
         return 1;
     }
     case N_FLIP: /* hitable.clj:375-381 */
-        if (!node_hit(sc, a[0], r, tmin, tmax, h)) return 0;
+        if (!node_hit(sc, a[0], r, tmin, tmax, h, rng)) return 0;
         h->n = vneg(h->n);
         return 1;
     case N_TRANSLATE: { /* hitable.clj:391-396 */
         ray_t tr = *r;
         tr.o = vsub(r->o, ld3(g));
-        if (!node_hit(sc, a[0], &tr, tmin, tmax, h)) return 0;
+        if (!node_hit(sc, a[0], &tr, tmin, tmax, h, rng)) return 0;
         h->p = vadd(h->p, ld3(g));
         return 1;
     }
@@ -400,25 +400,46 @@ static int node_hit(const rto_scene *sc, int n, const ray_t *r, real tmin, real 
         rr.o = V(cs * r->o.x - sn * r->o.z, r->o.y, sn * r->o.x + cs * r->o.z);
         rr.d = V(cs * r->d.x - sn * r->d.z, r->d.y, sn * r->d.x + cs * r->d.z);
         rr.time = r->time;
-        if (!node_hit(sc, a[0], &rr, tmin, tmax, h)) return 0;
+        if (!node_hit(sc, a[0], &rr, tmin, tmax, h, rng)) return 0;
         const v3 p = h->p, nn = h->n;
         h->p = V(cs * p.x + sn * p.z, p.y, (-(sn * p.x)) + cs * p.z);
         h->n = V(cs * nn.x + sn * nn.z, nn.y, (-(sn * nn.x)) + cs * nn.z);
         return 1;
     }
     case N_BOX: /* hitable.clj:491-494: hit? of the six sides' Hitlist */
-        return node_hit(sc, a[0], r, tmin, tmax, h);
+        return node_hit(sc, a[0], r, tmin, tmax, h, rng);
+    case N_MEDIUM: { /* hitable.clj:516-541 ConstantMedium: the boundary is hit twice on the whole line, the segment inside is
+                        clipped to [t-min, t-max], and ONE random number decides where (whether) the ray scatters inside */
+        const real FMAX = (real)3.4028234663852886e38;
+        hit_t h1, h2;
+        if (!node_hit(sc, a[0], r, -FMAX, FMAX, &h1, rng)) return 0;
+        if (!node_hit(sc, a[0], r, h1.t + (real)0.0001, FMAX, &h2, rng)) return 0;
+        real t1 = h1.t, t2 = h2.t;
+        if (t1 < tmin) t1 = tmin;
+        if (t2 > tmax) t2 = tmax;
+        if (!(t1 < t2)) return 0;
+        if (t1 < (real)0) t1 = 0;
+        const real mag = vmag(r->d);
+        const real dist_in = (t2 - t1) * mag;
+        const real hit_distance = -((real)log((double)rng_next(rng)) / (real)g[0]);
+        if (!(hit_distance < dist_in)) return 0;
+        h->t = t1 + hit_distance / mag;
+        h->p = point_at(r, h->t);
+        h->u = 0; h->v = 0; h->n = V(1, 0, 0);
+        h->prim = sc->node_prim[n]; h->mat = a[2];
+        return 1;
+    }
     case N_HITLIST: { /* hitable.clj:15-26 */
         int found = 0; real closest = tmax; hit_t tmp;
         for (int k = 0; k < a[1]; ++k)
-            if (node_hit(sc, sc->node_children[a[0] + k], r, tmin, closest, &tmp)) { found = 1; closest = tmp.t; *h = tmp; }
+            if (node_hit(sc, sc->node_children[a[0] + k], r, tmin, closest, &tmp, rng)) { found = 1; closest = tmp.t; *h = tmp; }
         return found;
     }
     case N_BVH: { /* hitable.clj:97-105: slab test, both children with the un-narrowed interval, ties -> right */
         const double o[3] = {r->o.x, r->o.y, r->o.z}, d[3] = {r->d.x, r->d.y, r->d.z};
         if (!rto_aabb_hit(g, g + 3, o, d, tmin, tmax)) return 0;
         hit_t hl, hr;
-        const int fl = node_hit(sc, a[0], r, tmin, tmax, &hl), fr = node_hit(sc, a[1], r, tmin, tmax, &hr);
+        const int fl = node_hit(sc, a[0], r, tmin, tmax, &hl, rng), fr = node_hit(sc, a[1], r, tmin, tmax, &hr, rng);
         if (fl && fr) { *h = (hl.t < hr.t) ? hl : hr; return 1; }
         if (fl) { *h = hl; return 1; }
         if (fr) { *h = hr; return 1; }
@@ -430,8 +451,8 @@ static int node_hit(const rto_scene *sc, int n, const ray_t *r, real tmin, real 
 }
 
 /* ---- hitable.clj:15-26 Hitlist: linear scan, each item tested with t-max = best so far ---- */
-static int hitlist_hit(const rto_scene *sc, const ray_t *r, real tmin, real tmax, hit_t *h) {
-    if (sc->n_nodes > 0) return node_hit(sc, sc->root, r, tmin, tmax, h);
+static int hitlist_hit(const rto_scene *sc, const ray_t *r, real tmin, real tmax, hit_t *h, rng_t *rng) {
+    if (sc->n_nodes > 0) return node_hit(sc, sc->root, r, tmin, tmax, h, rng);
     int found = 0;
     real closest = tmax;
     hit_t tmp;
@@ -505,6 +526,11 @@ static int scatter(const rto_scene *sc, const ray_t *rin, const hit_t *h, rng_t 
         }
         return 1;
     }
+    case MAT_ISOTROPIC: { /* shader.clj:129-138: (ray p (rand-in-unit-sphere) t) -- the new ray's TIME is the hit's t */
+        out->o = h->p; out->d = rand_in_unit_sphere(g); out->time = h->t;
+        *att = tex_sample(sc, sc->mat_tex[m], h->u, h->v, h->p);
+        return 1;
+    }
     default: /* DiffuseLight: scatter -> nil */
         return 0;
     }
@@ -552,7 +578,7 @@ static v3 color(const rto_scene *sc, ray_t r, int depth, rng_t *g, uint64_t *nra
     for (;;) {
         ++*nrays; /* metrics count-rays, core.clj:24 */
         hit_t h;
-        if (!hitlist_hit(sc, &r, T_MIN, T_MAX, &h)) return accum; /* core.clj:40-41 */
+        if (!hitlist_hit(sc, &r, T_MIN, T_MAX, &h, g)) return accum; /* core.clj:40-41 */
         ray_t sr; v3 att;
         int scat = depth > 0 ? scatter(sc, &r, &h, g, &sr, &att) : 0;
         v3 e = emitted(sc, &h);
@@ -663,7 +689,8 @@ RTO_API int rto_probe_hit(const rto_scene *sc, int n, const double *rays, double
         ray_t r = {ld3(q), ld3(q + 3), (real)q[6]};
         hit_t h; double *o = out + (size_t)k * 11;
         memset(o, 0, 11 * sizeof(double));
-        if (hitlist_hit(sc, &r, (real)tmin, (real)tmax, &h)) {
+        rng_t g = {0, 0}; /* a ConstantMedium draws inside hit?: the probe uses stream key 0 */
+        if (hitlist_hit(sc, &r, (real)tmin, (real)tmax, &h, &g)) {
             o[0] = 1; o[1] = h.prim; o[2] = h.t; o[3] = h.p.x; o[4] = h.p.y; o[5] = h.p.z;
             o[6] = h.n.x; o[7] = h.n.y; o[8] = h.n.z; o[9] = h.u; o[10] = h.v;
         }

@@ -10,12 +10,12 @@ from raytrace_clj_amd import flatten as fl
 from raytrace_clj_amd import hitable as H
 
 (N_SPHERE, N_UVSPHERE, N_MOVING, N_RECT_XY, N_RECT_XZ, N_RECT_YZ, N_TRIANGLE, N_FLIP, N_TRANSLATE, N_ROTATE_Y, N_HITLIST,
- N_BOX, N_BVH) = range(13)
+ N_BOX, N_BVH, N_MEDIUM) = range(14)
 
 
 def attach_tree(flat, world):
     leaves = []
-    fl._leaves(world, leaves, set())
+    fl._leaves(world, leaves, set())  # world primitives only (media included, their boundaries not)
     prim_index = {(id(o), chain, flip): i for i, (o, chain, flip) in enumerate(leaves)}
     mat_of_prim = flat.prim_mat
     kind, a, d, prim, children = [], [], [], [], []
@@ -25,10 +25,20 @@ def attach_tree(flat, world):
         return len(kind) - 1
 
     def leaf(k, o, dd, chain, flip):
+        if state["boundary"]:
+            return new(k, (0, 0, 0), dd, -1)
         i = prim_index[(id(o), chain, flip)]
         return new(k, (0, 0, int(mat_of_prim[i])), dd, i)
 
-    def walk(o, chain, flip):
+    state = {"boundary": False}
+
+    def walk(o, chain, flip, boundary=False):
+        if boundary:
+            state["boundary"] = True
+            try:
+                return walk(o, chain, flip)
+            finally:
+                state["boundary"] = False
         if isinstance(o, (list, tuple)):
             o = H.Hitlist(list(o))
         if isinstance(o, H.Hitlist):
@@ -58,6 +68,11 @@ def attach_tree(flat, world):
         if isinstance(o, H.RotateY):
             n = new(N_ROTATE_Y, dd=[o.sin_theta, o.cos_theta])
             a[n] = [walk(o.obj, chain + ((fl.XFORM_ROTATE_Y, (float(o.sin_theta), float(o.cos_theta), 0.0)),), flip), 0, 0]
+            return n
+        if isinstance(o, H.ConstantMedium):
+            i = prim_index[(id(o), chain, flip)]
+            n = new(N_MEDIUM, dd=[o.density], p=i)
+            a[n] = [walk(o.boundary, chain, flip, boundary=True), 0, int(mat_of_prim[i])]
             return n
         if isinstance(o, H.MovingSphere):
             return leaf(N_MOVING, o, list(o.center0) + [o.radius] + list(o.center1) + [o.t0, o.t1], chain, flip)

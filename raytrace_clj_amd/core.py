@@ -100,6 +100,10 @@ class DeviceScene:
             vec = np.ascontiguousarray(f.perlin_vectors, np.float64)
             perm = np.ascontiguousarray(f.perlin_perm, np.int32)
             check(_ffi.lib().rtmi_scene_set_perlin(h, ptr(vec), ptr(perm)))
+        calls = getattr(f, "media_calls", None)
+        if calls is not None and len(calls):  # ConstantMedium hit? invocation order (a medium in a one-item bvh leaf is asked twice)
+            calls = np.ascontiguousarray(calls, np.int32)
+            check(_ffi.lib().rtmi_scene_set_media_calls(h, len(calls), ptr(calls)))
         images = getattr(f, "images", None) or []
         if images:  # ImageMap pixels (texture.clj:126-133)
             imgs = [np.ascontiguousarray(im, np.uint8) for im in images]

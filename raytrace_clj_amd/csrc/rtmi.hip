@@ -92,20 +92,22 @@ __device__ inline void scan_bvh_dispatch(SceneRef sc, int *, const Path<float> &
 // hit? of the whole world for the lane's ray (closest hit, t in (t-min, t-max); core.clj:25 passes 0.001, Float/MAX_VALUE).
 // MULTI (LDS variants only): the static spheres do not fit one LDS tile; every thread of the workgroup must call this.
 // section 8(f3) scenes (FP64 only): BVH or culled flat scan over mixed primitive kinds with the any-order tie rule
-__device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, const Path<double> &P, bool active, double tmin, double tmax, double &best_t, int &best_i) {
+__device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<double> &P, bool active, double tmin, double tmax, double &best_t, int &best_i) {
     best_t = tmax; best_i = -1;
     if (!active) return;
     const double a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
     ExtHit H = {tmax, 0x7fffffff, -1, false};
     if (bvh) scan_bvh_ext(sc, stack, P, a, tmin, H);
     else scan_all_cull_ext(sc, P, a, tmin, H);
+    // media: after the surfaces, in primitive-index order = the order the reference's descent calls their hit? (and draws)
+    for (int k = 0; k < sc.n_media; ++k) ext_medium_test(sc, sc.media_idx[k], P, tmin, tmax, H);
     best_i = ext_winner(H);
     if (best_i >= 0) best_t = H.t;
 }
-__device__ inline void intersect_ext(SceneRef, int *, bool, const Path<float> &, bool, float, float tmax, float &best_t, int &best_i) { best_t = tmax; best_i = -1; }
+__device__ inline void intersect_ext(SceneRef, int *, bool, Path<float> &, bool, float, float tmax, float &best_t, int &best_i) { best_t = tmax; best_i = -1; }
 
 template <typename R, bool MULTI, int VARIANT, bool EXT = false>
-__device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, const Path<R> &P,
+__device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, Path<R> &P,
                                        bool active, R tmin, R tmax, R &best_t, int &best_i) {
     if (EXT) { intersect_ext(sc, reinterpret_cast<int *>(lds), VARIANT == SCAN_BVH, P, active, tmin, tmax, best_t, best_i); return; }
     best_t = tmax;
@@ -487,6 +489,7 @@ struct rtmi_scene {
     bool uses_perlin = false; // a Perlin texture is present: rtmi_scene_set_perlin must have been called before rendering
     int max_image = -1;       // highest ImageMap index: rtmi_scene_set_images must cover it
     bool have_perlin = false;
+    std::vector<int> host_kind; // primitive kinds (boundary flag removed), for argument checks
 };
 
 namespace {
@@ -758,12 +761,13 @@ bool prim_world_box(int kind, const double *g, const int32_t *xf_kind, const dou
 }
 
 // fills d.bvh_* ; returns the node array to upload.  wbox[i] / bounded[i]: prim_world_box of every primitive.
-std::vector<float> build_bvh(DevScene &d, int n_prims, const int32_t *prim_kind, const std::vector<BvhBox> &wbox, const std::vector<char> &bounded, const double *cam) {
+std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, const std::vector<BvhBox> &wbox, const std::vector<char> &bounded, const double *cam) {
     BvhBuilder B;
     std::vector<BvhItem> all;
     double obound = 0.0;
     for (int k = 0; k < 3; ++k) obound = std::max(obound, std::fabs(cam[k]));
     for (int i = 0; i < n_prims; ++i) {
+        if (prim_kind[i] == RTMI_PRIM_MEDIUM) continue; // media are not surfaces (ext_medium_test)
         BvhItem it; it.idx = i;
         if (bounded[(size_t)i]) {
             it.b = wbox[(size_t)i];
@@ -926,12 +930,13 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
             }
     }
     for (int m = 0; m < n_mats; ++m) {
-        if (mat_kind[m] < RTMI_MAT_LAMBERTIAN || mat_kind[m] > RTMI_MAT_DIFFUSE_LIGHT) return fail(RTMI_E_UNSUPPORTED, "material %d: kind %d unsupported on GPU path", m, mat_kind[m]);
+        if (mat_kind[m] < RTMI_MAT_LAMBERTIAN || mat_kind[m] > RTMI_MAT_ISOTROPIC) return fail(RTMI_E_UNSUPPORTED, "material %d: kind %d unsupported on GPU path", m, mat_kind[m]);
         if (mat_kind[m] != RTMI_MAT_DIELECTRIC && (mat_tex[m] < 0 || mat_tex[m] >= n_tex)) return fail(RTMI_E_ARG, "material %d: texture index %d invalid", m, mat_tex[m]);
     }
     std::vector<double> stat_geom, mov_geom, stat4_d;
     std::vector<float> stat4_f;
     bool has_ext = false, uses_perlin = false;
+    int n_world = 0, n_media = 0, media[16];
     int max_image = -1;
     for (int t = 0; t < n_tex; ++t) {
         if (tex_kind[t] > RTMI_TEX_CHECKER) has_ext = true; // section 8(f4) textures live in the EXT kernels only
@@ -944,10 +949,26 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     }
     std::vector<int> stat_orig, mov_orig, pk((size_t)n_prims), pm((size_t)n_prims);
     for (int i = 0; i < n_prims; ++i) {
-        const int kind = prim_kind[i];
-        if (kind < RTMI_PRIM_SPHERE || kind > RTMI_PRIM_TRIANGLE) return fail(RTMI_E_UNSUPPORTED, "primitive %d: kind %d unsupported on GPU path", i, kind);
+        const int kind = prim_kind[i] & ~RTMI_PRIM_BOUNDARY;
+        const bool is_boundary = (prim_kind[i] & RTMI_PRIM_BOUNDARY) != 0;
+        if (kind < RTMI_PRIM_SPHERE || kind > RTMI_PRIM_MEDIUM) return fail(RTMI_E_UNSUPPORTED, "primitive %d: kind %d unsupported on GPU path", i, prim_kind[i]);
+        if (is_boundary && kind == RTMI_PRIM_MEDIUM) return fail(RTMI_E_UNSUPPORTED, "primitive %d: a medium inside a medium's boundary is unsupported", i);
+        if (!is_boundary && n_world != i) return fail(RTMI_E_ARG, "primitive %d: boundary primitives must come after all world primitives", i);
+        if (!is_boundary) n_world = i + 1;
         if (prim_mat[i] < 0 || prim_mat[i] >= n_mats) return fail(RTMI_E_ARG, "primitive %d: material index %d invalid", i, prim_mat[i]);
         pk[(size_t)i] = kind; pm[(size_t)i] = prim_mat[i];
+        if (kind == RTMI_PRIM_MEDIUM) {
+            const double *mg = prim_geom + (size_t)i * RTMI_PRIM_STRIDE;
+            const int fb = (int)mg[1], nb = (int)mg[2];
+            if (!(mg[0] == mg[0]) || fb < 0 || nb <= 0 || fb + nb > n_prims) return fail(RTMI_E_ARG, "medium %d: boundary range [%d, %d) invalid", i, fb, fb + nb);
+            for (int q = fb; q < fb + nb; ++q) if (!(prim_kind[q] & RTMI_PRIM_BOUNDARY)) return fail(RTMI_E_ARG, "medium %d: primitive %d is not flagged RTMI_PRIM_BOUNDARY", i, q);
+            if (mat_kind[prim_mat[i]] != RTMI_MAT_ISOTROPIC) return fail(RTMI_E_ARG, "medium %d: the phase function must be RTMI_MAT_ISOTROPIC", i);
+            if (n_media >= 16) return fail(RTMI_E_UNSUPPORTED, "more than 16 ConstantMedium records in one scene");
+            media[n_media++] = i;
+            has_ext = true;
+            continue;
+        }
+        if (is_boundary) { has_ext = true; continue; }
         const double *g = prim_geom + (size_t)i * RTMI_PRIM_STRIDE;
         const int xf_first = prim_xform ? prim_xform[2 * i] : 0, xf_count = prim_xform ? prim_xform[2 * i + 1] : 0;
         if (xf_count < 0 || xf_first < 0 || xf_first + xf_count > n_xforms) return fail(RTMI_E_ARG, "primitive %d: xform range [%d, %d) invalid", i, xf_first, xf_first + xf_count);
@@ -1006,10 +1027,17 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     }
     for (int i = 0; i < n_prims; ++i) {
         const double *g = prim_geom + (size_t)i * RTMI_PRIM_STRIDE;
-        const int kind = prim_kind[i];
+        const int kind = prim_kind[i] & ~RTMI_PRIM_BOUNDARY;
         const int xf_first = prim_xform ? prim_xform[2 * i] : 0, xf_count = prim_xform ? prim_xform[2 * i + 1] : 0;
         const int info[4] = {kind, prim_flip ? (prim_flip[i] & 1) : 0, xf_first, xf_count};
         ext_info.insert(ext_info.end(), info, info + 4);
+        if (kind == RTMI_PRIM_MEDIUM) { // not a surface: no box, a neutral cull entry (ext_prim_test ignores it), evaluated by ext_medium_test
+            exact12.insert(exact12.end(), {g[0], g[1], g[2], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0});
+            cull_c.insert(cull_c.end(), {0.0f, 0.0f, 0.0f});
+            cull_r2.push_back(0.0f);
+            cull_w.push_back(0.0f);
+            continue;
+        }
         bounded[(size_t)i] = prim_world_box(kind, g, xform_kind, xform_param, xf_first, xf_count, t_lo, t_hi, wbox[(size_t)i]);
         const bool moving = kind == RTMI_PRIM_MOVING;
         const volatile double r2d = g[3] * g[3];
@@ -1087,8 +1115,11 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
         }
         cull20.insert(cull20.end(), rec, rec + 20);
     }
-    d.n_all = n_prims; d.cull_t_lo = t_lo; d.cull_t_hi = t_hi;
-    const std::vector<float> bvh_nodes = build_bvh(d, n_prims, prim_kind, wbox, bounded, cam);
+    d.n_all = n_world; d.cull_t_lo = t_lo; d.cull_t_hi = t_hi; // the scans walk the world; boundary primitives are reached only through their medium
+    d.n_media = n_media;
+    for (int k = 0; k < n_media; ++k) d.media_idx[k] = media[k];
+    s->host_kind = pk;
+    const std::vector<float> bvh_nodes = build_bvh(d, n_world, pk.data(), wbox, bounded, cam);
     if (!rc) rc = upload(s, bvh_nodes, &d.bvh_nodes);
     d.has_ext = has_ext ? 1 : 0;
     if (!rc) rc = upload(s, ext_info, &d.ext_info);
@@ -1144,6 +1175,17 @@ RTMI_EXPORT int rtmi_scene_set_perlin(rtmi_scene *s, const double *vectors, cons
     if (!rc) rc = upload(s, p, &s->dev.perlin_perm);
     if (rc) return rc;
     s->have_perlin = true;
+    return reupload_descriptor(s);
+}
+
+RTMI_EXPORT int rtmi_scene_set_media_calls(rtmi_scene *s, int32_t n_calls, const int32_t *calls) {
+    if (!scene_ok(s)) return fail(RTMI_E_STATE, "invalid scene handle");
+    if (n_calls < 0 || n_calls > 32 || (n_calls > 0 && !calls)) return fail(RTMI_E_ARG, "n_calls must be 0..32");
+    for (int k = 0; k < n_calls; ++k)
+        if (calls[k] < 0 || calls[k] >= s->n_prims || s->host_kind[(size_t)calls[k]] != RTMI_PRIM_MEDIUM) return fail(RTMI_E_ARG, "calls[%d] = %d is not a medium primitive", k, calls[k]);
+    s->dev.n_media = n_calls;
+    for (int k = 0; k < n_calls; ++k) s->dev.media_idx[k] = calls[k];
+    HIP_TRY(hipSetDevice(s->ctx->device));
     return reupload_descriptor(s);
 }
 

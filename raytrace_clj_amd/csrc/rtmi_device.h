@@ -39,6 +39,8 @@ struct DevScene {
     int has_ext;             // any primitive kind > 2, any instance wrapper, any flip
     const int *ext_info;     // [n_all][4]: kind, FlipNormals parity, first xform, xform count (outermost first)
     const double *ext_xf;    // [n_xforms][4]: 0 | offset.xyz  (Translate)   or   1 | sin, cos, 0  (RotateY)
+    int n_media;             // hit? invocations of ConstantMedium primitives (hitable.clj:516) per ray, in the reference's call order
+    int media_idx[32];       // (a medium may appear twice: rtmi_scene_set_media_calls); exact12 = density, first boundary prim, count
     // section 8(f4): perlin.clj:6-17 tables (seeded scene data) and ImageMap pixels (texture.clj:126-133)
     const double *perlin_vec; // [256][3]
     const int *perlin_perm;   // [3][256]
@@ -694,6 +696,7 @@ __device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P
     const LocalRay r = ext_local_ray(sc, info.z, info.w, P);
     const double *g = sc.exact12 + (size_t)idx * 12;
     const int kind = info.x;
+    if (kind == RTMI_PRIM_MEDIUM) return; // media are evaluated after the surfaces, in index order (ext_medium_test)
     if (kind <= RTMI_PRIM_MOVING) {
         Prim4<double> s;
         s.cx = g[0]; s.cy = g[1]; s.cz = g[2]; s.r2 = g[3];
@@ -725,6 +728,33 @@ __device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P
         double u, v, t;
         if (tri_mt(g, r, u, v, t) && t >= tmin) ext_update(H, t, idx, true);
     }
+}
+
+// ConstantMedium.hit? (hitable.clj:518-541): closest boundary hit on the whole line, closest boundary hit after it, the
+// segment between them clipped to [t-min, t-max]; then ONE draw of the path's stream: hit-distance = -(log xi)/density
+// against the length of the segment decides whether (where) the ray scatters inside.  t-min/t-max are the caller's
+// un-narrowed interval, as in the reference's bvh-node descent (hitable.clj:99-105).
+__device__ inline void ext_medium_test(SceneRef sc, int idx, Path<double> &P, double tmin, double tmax, ExtHit &H) {
+    const double FMAX = 3.4028234663852886e38;
+    const double *g = sc.exact12 + (size_t)idx * 12;
+    const int first = (int)g[1], count = (int)g[2];
+    ExtHit h1 = {FMAX, 0x7fffffff, -1, false};
+    for (int k = 0; k < count; ++k) ext_prim_test(sc, first + k, P, -FMAX, h1);
+    if (!h1.any) return;
+    ExtHit h2 = {FMAX, 0x7fffffff, -1, false};
+    for (int k = 0; k < count; ++k) ext_prim_test(sc, first + k, P, h1.t + 0.0001, h2);
+    if (!h2.any) return;
+    double t1 = h1.t, t2 = h2.t;
+    if (t1 < tmin) t1 = tmin;
+    if (t2 > tmax) t2 = tmax;
+    if (!(t1 < t2)) return;
+    if (t1 < 0.0) t1 = 0.0;
+    const int4 info = reinterpret_cast<const int4 *>(sc.ext_info)[idx];
+    const LocalRay r = ext_local_ray(sc, info.z, info.w, P);
+    const double mag = ::sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
+    const double dist_in = (t2 - t1) * mag;
+    const double hit_distance = -(::log(next_uniform(P)) / g[0]);
+    if (hit_distance < dist_in) ext_update(H, t1 + hit_distance / mag, idx, true);
 }
 
 // the flat scan (FP32 cull + exact test) over all primitives
@@ -885,6 +915,8 @@ __device__ inline void resolve_hit_ext(SceneRef sc, const Path<double> &P, doubl
             h.u = 1.0 - (phi + PI) / (2.0 * PI);
             h.v = (theta + PI / 2.0) / PI;
         }
+    } else if (kind == RTMI_PRIM_MEDIUM) { // hitable.clj:536-540: uv [0 0] and normal (1,0,0) are arbitrary
+        nx = 1.0; ny = 0.0; nz = 0.0;
     } else if (kind <= RTMI_PRIM_RECT_YZ) {
         int ax, ua, va;
         rect_axes(kind, ax, ua, va);
@@ -928,6 +960,7 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
     const bool is_light = mk == RTMI_MAT_DIFFUSE_LIGHT;
     const bool live = !is_light && P.depth > 0; // core.clj:27: (and (pos? depth) (scatter ...))
     const bool is_lamb = live && mk == RTMI_MAT_LAMBERTIAN, is_metal = live && mk == RTMI_MAT_METAL, is_diel = live && mk == RTMI_MAT_DIELECTRIC;
+    const bool is_iso = F4 && live && mk == RTMI_MAT_ISOTROPIC; // shader.clj:129-138, the phase function of ConstantMedium
     bool scat = false;
     R sdx = R(0), sdy = R(0), sdz = R(0); // scattered direction
     R atr = R(1), atg = R(1), atb = R(1);  // attenuation
@@ -940,11 +973,15 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
     }
     // phase 2 -- rand-in-unit-sphere: Lambertian (shader.clj:32) and Metal (shader.clj:53; drawn even when fuzz = 0)
     R rx = R(0), ry = R(0), rz = R(0);
-    if (is_lamb || is_metal) rand_in_unit_sphere(P, rx, ry, rz);
+    if (is_lamb || is_metal || is_iso) rand_in_unit_sphere(P, rx, ry, rz);
     // phase 3 -- directions
     if (is_lamb) { // shader.clj:29-34: target = (p + normal) + rand; dir = target - p
         const R tx = (px + nx) + rx, ty = (py + ny) + ry, tz = (pz + nz) + rz;
         sdx = tx - px; sdy = ty - py; sdz = tz - pz;
+        scat = true;
+    } else if (is_iso) { // (ray p (rand-in-unit-sphere) t): the scattered ray's TIME is the hit's t (shader.clj:136)
+        sdx = rx; sdy = ry; sdz = rz;
+        P.time = h.t;
         scat = true;
     } else if (is_metal) { // shader.clj:46-57 + reflect shader.clj:6-9
         const R fuzz = (R)sc.mat_param[mat];
@@ -978,7 +1015,7 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
     }
     // phase 4 -- ONE texture evaluation: emitted of DiffuseLight (shader.clj:118-119) or the albedo of a successful
     // Lambertian / Metal scatter (shader.clj:34,57)
-    if (is_light || is_lamb || (is_metal && scat)) {
+    if (is_light || is_lamb || is_iso || (is_metal && scat)) {
         R tr, tg, tb;
         tex_sample<R, F4>(sc, sc.mat_tex[mat], h.u, h.v, px, py, pz, tr, tg, tb);
         if (is_light) { P.cr = P.cr + P.ar * tr; P.cg = P.cg + P.ag * tg; P.cb = P.cb + P.ab * tb; } // core.clj:37-39

