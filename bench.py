@@ -27,6 +27,9 @@ CONFIGS = {
     "C5": (1920, 1080, 4096, 11, False, (0.1, 0.2)),
     # section 8(f3): the classic Cornell box (scene.clj:230-316), 18 rectangles through Translate/RotateY/FlipNormals
     "CB": (600, 600, 256, 0, False, None),
+    # the scene `lein run` renders as shipped (core.clj:90, scene.clj:415-489): 400 boxes, 1000 instanced spheres, two
+    # ConstantMedium volumes, marble / image textures, a moving sphere, a rectangle light
+    "FINAL": (500, 500, 128, 0, False, None),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6     # vector FP64 (spec)
@@ -100,9 +103,14 @@ def main():
 
     nx, ny, ns1, n, moving, mix = CONFIGS[args.config]
     ns = ns1 * world  # weak scaling: per-GPU work fixed
-    scene = r.scene.make_cornell_box(nx, ny) if args.config == "CB" else r.scene.make_random_scene(nx, ny, n, moving, mix=mix)
+    if args.config == "CB":
+        scene = r.scene.make_cornell_box(nx, ny)
+    elif args.config == "FINAL":
+        scene = r.scene.make_final(nx, ny)
+    else:
+        scene = r.scene.make_random_scene(nx, ny, n, moving, mix=mix)
     flat = r.flatten.flatten(scene)
-    if args.config == "CB":  # the CPU baseline evaluates the nested records like the reference does
+    if args.config in ("CB", "FINAL"):  # the CPU baseline evaluates the nested records like the reference does
         from oracle.tree import attach_tree
         attach_tree(flat, scene["world"])
     ctx = r.Context(local_rank, timing=True)
@@ -191,6 +199,8 @@ def main():
             "config": {"workload": ("%s: %dx%dx%dspp classic Cornell box (%d rectangles via Translate/RotateY/FlipNormals), depth 50, "
                                     "seeded counter RNG; accel=%s; tiles dealt round-robin to %d GPU(s)" % (args.config, nx, ny, ns, n_prims, main_accel, world))
                        if args.config == "CB" else
+                       ("%s: %dx%dx%dspp make-final (scene.clj:415-489; %d primitives), depth 50; accel=%s; %d GPU(s)" % (args.config, nx, ny, ns, n_prims, main_accel, world))
+                       if args.config == "FINAL" else
                        "%s: %dx%dx%dspp Shirley cover scene n=%d (%d spheres%s), depth 50, thin-lens camera, "
                        "seeded counter RNG; accel=%s; tiles dealt round-robin to %d GPU(s)" % (
                            args.config, nx, ny, ns, n, n_prims, ", moving" if moving else "", main_accel, world),

@@ -294,16 +294,35 @@ def save_ppm(path, rgb8):
         f.write(np.ascontiguousarray(rgb8, np.uint8).tobytes())
 
 
+SCENES = {  # the scene choices of core.clj:82-90 (there: commented-out lines; here: the 5th argument)
+    "random": lambda s, nx, ny: s.make_random_scene(nx, ny, 11, True),      # core.clj:89, the Shirley cover scene
+    "final": lambda s, nx, ny: s.make_final(nx, ny),                        # core.clj:90, the line that is active as shipped
+    "two-spheres": lambda s, nx, ny: s.make_two_spheres(nx, ny),            # core.clj:82
+    "two-perlin-spheres": lambda s, nx, ny: s.make_two_perlin_spheres(nx, ny),
+    "textured-sphere": lambda s, nx, ny: s.make_textured_sphere(nx, ny),
+    "subsurface-sphere": lambda s, nx, ny: s.make_subsurface_sphere(nx, ny),
+    "two-triangles": lambda s, nx, ny: s.make_two_triangles(nx, ny),
+    "example-light": lambda s, nx, ny: s.make_example_light(nx, ny),
+    "cornell-box": lambda s, nx, ny: s.make_cornell_box(nx, ny, False),     # core.clj:88 passes classic = false
+    "cornell-box-classic": lambda s, nx, ny: s.make_cornell_box(nx, ny, True),
+}
+
+
 def main(argv=None):
-    """lein-run compatible: `name nx ny ns` (core.clj:73-80); renders the cover scene (core.clj:89)."""
+    """lein-run compatible: `name nx ny ns [win|scene]` (core.clj:73-80).  The reference picks its scene by editing the
+    source (core.clj:82-90); here the 5th argument names it (default: the cover scene; "true"/"win", the reference's
+    window switch, is accepted and ignored -- there is no display on this path)."""
     from . import scene as scenes
     argv = list(sys.argv[1:] if argv is None else argv)
     name = argv[0] if len(argv) > 0 else "render.ppm"
     nx = int(argv[1]) if len(argv) > 1 else 200
     ny = int(argv[2]) if len(argv) > 2 else 100
     nr = int(argv[3]) if len(argv) > 3 else 100
+    which = argv[4] if len(argv) > 4 and argv[4] not in ("true", "win") else "random"
+    if which not in SCENES:
+        raise SystemExit("unknown scene %r; one of %s" % (which, ", ".join(sorted(SCENES))))
     tstart = time.time()
-    sc = scenes.make_random_scene(nx, ny, 11, True)
+    sc = SCENES[which](scenes, nx, ny)
     lin, rgb8, cnt = render(sc, nx, ny, nr)
     elapsed = time.time() - tstart
     print("%.2fs, %d%%, ETA %.2fs" % (elapsed, 100, 0.0))  # display.clj:20-24

@@ -1121,6 +1121,10 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     s->host_kind = pk;
     const std::vector<float> bvh_nodes = build_bvh(d, n_world, pk.data(), wbox, bounded, cam);
     if (!rc) rc = upload(s, bvh_nodes, &d.bvh_nodes);
+    std::vector<int> moving_all;
+    for (int i = 0; i < n_world; ++i) if (pk[(size_t)i] == RTMI_PRIM_MOVING) moving_all.push_back(i);
+    d.n_moving_all = (int)moving_all.size();
+    if (!rc) rc = upload(s, moving_all, &d.moving_all);
     d.has_ext = has_ext ? 1 : 0;
     if (!rc) rc = upload(s, ext_info, &d.ext_info);
     if (!rc) rc = upload(s, ext_xf, &d.ext_xf);

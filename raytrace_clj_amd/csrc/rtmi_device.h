@@ -34,7 +34,9 @@ struct DevScene {
     int bvh_root;            // child code: >= 0 node index, < 0 = ~(original primitive index | moving << 30), 0x7fffffff = empty
     int n_big;               // primitives too large to bound usefully (sky dome, ground): always tested exactly
     int big_idx[16];
-    float bvh_obound;        // rays starting outside [-obound, obound]^3 bypass the float traversal
+    float bvh_obound;        // rays starting outside [-obound, obound]^3 widen every box by 2^-22 |o| themselves
+    int n_moving_all;        // all MovingSphere world primitives (tested exhaustively for rays outside the shutter interval)
+    const int *moving_all;
     // section 8(f3): rectangles / triangles and FlipNormals / Translate / RotateY instances (hitable.clj:269-511, 548-581)
     int has_ext;             // any primitive kind > 2, any instance wrapper, any flip
     const int *ext_info;     // [n_all][4]: kind, FlipNormals parity, first xform, xform count (outermost first)
@@ -552,16 +554,22 @@ __device__ inline void exact_prim_test_lane(const double *exact12, int code, con
 // Conservative slab test in float, FMA form: t = plane * inv_d + (-o * inv_d).  Error budget: the rounding of
 // c = fl(-o_f * inv) and of the fma are each equivalent to moving the plane by <= 2^-24 |o| (plus a relative 2u on t), and
 // |fl32(o) - o| <= 2^-24 |o|; the box planes were rounded outward and inflated by 2^-22 * obound >= 4 * 2^-24 |o| on the
-// host, which covers all three for every safe ray (|o| <= obound).  The remaining relative error (<= 4u with the rounding
-// of inv) is absorbed by lowering the entry distance and raising the exit distance by 8u before comparing.
+// host, which covers all three for every ray with |o| <= obound.  A ray that starts OUTSIDE the scene bound (FAR: e.g.
+// after scattering in a scene-sized ConstantMedium) widens every slab by its own e = 2^-22 |o|_inf instead (ex = e |inv_x|,
+// ...).  The remaining relative error (<= 4u with the rounding of inv) is absorbed by lowering the entry distance and
+// raising the exit distance by 8u before comparing.
+template <bool FAR>
 __device__ inline bool box_hit(const float lo0, const float lo1, const float lo2, const float hi0, const float hi1, const float hi2,
                                const float cx, const float cy, const float cz, const float ix, const float iy, const float iz,
-                               const float tmin_lo, const float best_hi, float &tnear) {
+                               const float ex, const float ey, const float ez, const float tmin_lo, const float best_hi, float &tnear) {
     const float ax = fmaf(lo0, ix, cx), bx = fmaf(hi0, ix, cx);
     const float ay = fmaf(lo1, iy, cy), by = fmaf(hi1, iy, cy);
     const float az = fmaf(lo2, iz, cz), bz = fmaf(hi2, iz, cz);
-    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    float nx = fminf(ax, bx), ny = fminf(ay, by), nz = fminf(az, bz);
+    float fx = fmaxf(ax, bx), fy = fmaxf(ay, by), fz = fmaxf(az, bz);
+    if (FAR) { nx -= ex; ny -= ey; nz -= ez; fx += ex; fy += ey; fz += ez; }
+    float tn = fmaxf(fmaxf(nx, ny), nz);
+    float tf = fminf(fminf(fx, fy), fz);
     const float ku = 8.0f * 5.9604645e-08f;
     tn = fmaf(-ku, fabsf(tn), tn);
     tf = fmaf(ku, fabsf(tf), tf);
@@ -575,41 +583,45 @@ __device__ inline float float_up(double x) { // smallest float >= x (x finite, |
     return f;
 }
 
-// stack: LDS, one column per thread (stack[level * blockDim.x + tid]: conflict-free)
-__device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, double &best_t, int &best_i) {
-    const bool behind_ok = tmin >= 0.0;
-    const double *exact12 = sc.exact12;
-    // rays the float traversal cannot bound take the exact flat scan (all primitives, original order) instead
-    const float ox = (float)P.ox, oy = (float)P.oy, oz = (float)P.oz;
+// what the float traversal needs to know about a ray; ok = false: take the exact flat scan instead
+struct BvhRay { float ox, oy, oz, ix, iy, iz, cx, cy, cz, ex, ey, ez, tmin_lo; bool ok, far, time_ok; };
+__device__ inline BvhRay make_bvh_ray(SceneRef sc, const Path<double> &P, double a, double tmin) {
+    BvhRay r;
+    r.ox = (float)P.ox; r.oy = (float)P.oy; r.oz = (float)P.oz;
     const float dx = (float)P.dx, dy = (float)P.dy, dz = (float)P.dz;
     const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-    const float ob = sc.bvh_obound;
-    const bool safe = (fabsf(ox) <= ob) && (fabsf(oy) <= ob) && (fabsf(oz) <= ob) && (dmax < 1e15f) && (dmax > 1e-15f) &&
-                      (fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= 1e-12f * dmax) && (a > 1e-30) && (a < 1e30) &&
-                      (P.time >= sc.cull_t_lo) && (P.time <= sc.cull_t_hi) && (tmin > -1e30) && (tmin < 1e30);
-    if (!safe) {
-        scan_all_cull(sc, P, a, tmin, best_t, best_i);
-        return;
-    }
-    // 1. the big primitives (sky dome, ground, ...): exact test, ascending Hitlist index
-    for (int k = 0; k < sc.n_big; ++k) exact_prim_test(exact12, sc.big_idx[k], sc.big_idx[k], P, a, tmin, behind_ok, best_t, best_i);
-    // 2. per-lane traversal, "while-while": every lane descends until it holds a leaf (or is done); then all lanes
-    //    holding a leaf run the exact FP64 test together -- the expensive FP64 code is not interleaved with box tests
+    const float omax = fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fabsf(r.oz));
+    // not boundable in float: non-finite values, a vanishing direction component (1/d would overflow), absurd magnitudes
+    r.ok = (omax < 1e15f) && (dmax < 1e15f) && (dmax > 1e-15f) && (fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= 1e-12f * dmax) &&
+           (a > 1e-30) && (a < 1e30) && (tmin > -1e30) && (tmin < 1e30) && (sc.bvh_obound >= 0.0f);
+    r.far = omax > sc.bvh_obound;
+    r.time_ok = (P.time >= sc.cull_t_lo) && (P.time <= sc.cull_t_hi); // else the MovingSphere boxes do not bound this ray's spheres
+    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+    r.cx = -r.ox * r.ix; r.cy = -r.oy * r.iy; r.cz = -r.oz * r.iz;
+    const float e = r.far ? omax * (1.0001f / 4194304.0f) : 0.0f;
+    r.ex = e * fabsf(r.ix); r.ey = e * fabsf(r.iy); r.ez = e * fabsf(r.iz);
+    r.tmin_lo = r.ok ? -float_up(-tmin) : 0.0f;
+    return r;
+}
+
+// Per-lane traversal, "while-while": every lane descends until it holds a leaf (or is done); then all lanes holding a
+// leaf run the exact FP64 test together -- the expensive FP64 code is not interleaved with box tests.  Stack: LDS, one
+// column per thread (stack[level * blockDim.x + tid]: conflict-free).  leaf(code) runs the exact test, best() returns the
+// current float upper bound of the closest t.
+template <bool FAR, typename Leaf, typename BestHi>
+__device__ inline void bvh_traverse(SceneRef sc, int *stack, const BvhRay &r, Leaf leaf, BestHi best) {
     int node = sc.bvh_root;
     if (node == RTMI_BVH_EMPTY) return;
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    const float cx = -ox * ix, cy = -oy * iy, cz = -oz * iz;
-    const float tmin_lo = -float_up(-tmin);
     const int tid = threadIdx.x, stride = blockDim.x;
     int sp = 0;
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.bvh_nodes);
-    float best_hi = best_t < 3.0e38 ? float_up(best_t) : 3.4028235e38f;
+    float best_hi = best();
     while (node != RTMI_BVH_EMPTY) {
         while (node >= 0 && node != RTMI_BVH_EMPTY) { // inner node: both child boxes come with it (one 64-byte record)
             const float4 n0 = nodes[(size_t)node * 4], n1 = nodes[(size_t)node * 4 + 1], n2 = nodes[(size_t)node * 4 + 2], n3 = nodes[(size_t)node * 4 + 3];
             float tl, tr;
-            const bool hl = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, cx, cy, cz, ix, iy, iz, tmin_lo, best_hi, tl);
-            const bool hr = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, cx, cy, cz, ix, iy, iz, tmin_lo, best_hi, tr);
+            const bool hl = box_hit<FAR>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r.cx, r.cy, r.cz, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tmin_lo, best_hi, tl);
+            const bool hr = box_hit<FAR>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r.cx, r.cy, r.cz, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tmin_lo, best_hi, tr);
             const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
             if (hl && hr) {
                 const bool left_first = tl <= tr;
@@ -622,12 +634,32 @@ __device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<double> &P, 
             else node = RTMI_BVH_EMPTY;
         }
         if (node != RTMI_BVH_EMPTY) { // leaf: one primitive, exact FP64 test
-            exact_prim_test_lane(exact12, node, P, a, tmin, behind_ok, best_t, best_i);
-            best_hi = best_t < 3.0e38 ? float_up(best_t) : 3.4028235e38f;
+            leaf(node);
+            best_hi = best();
             if (sp > 0) { --sp; node = stack[sp * stride + tid]; }
             else node = RTMI_BVH_EMPTY;
         }
     }
+}
+
+__device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, double &best_t, int &best_i) {
+    const bool behind_ok = tmin >= 0.0;
+    const double *exact12 = sc.exact12;
+    const BvhRay r = make_bvh_ray(sc, P, a, tmin);
+    if (!r.ok) { // rays the float traversal cannot bound take the exact flat scan (all primitives, original order) instead
+        scan_all_cull(sc, P, a, tmin, best_t, best_i);
+        return;
+    }
+    // 1. the big primitives (sky dome, ground, ...): exact test, ascending Hitlist index
+    for (int k = 0; k < sc.n_big; ++k) exact_prim_test(exact12, sc.big_idx[k], sc.big_idx[k], P, a, tmin, behind_ok, best_t, best_i);
+    // 2. the tree
+    auto leaf = [&](int code) { exact_prim_test_lane(exact12, code, P, a, tmin, behind_ok, best_t, best_i); };
+    auto best = [&]() { return best_t < 3.0e38 ? float_up(best_t) : 3.4028235e38f; };
+    if (__any(r.far ? 1 : 0)) bvh_traverse<true>(sc, stack, r, leaf, best);
+    else bvh_traverse<false>(sc, stack, r, leaf, best);
+    // 3. a ray outside the shutter interval: the MovingSphere boxes were built for [t_lo, t_hi], so test every moving sphere exactly
+    if (!r.time_ok)
+        for (int k = 0; k < sc.n_moving_all; ++k) exact_prim_test_lane(exact12, ~(sc.moving_all[k] | 0x40000000), P, a, tmin, behind_ok, best_t, best_i);
 }
 
 // ==== section 8(f3): RectXY/XZ/YZ (hitable.clj:269-363), Triangle (548-571), FlipNormals (375-381), Translate (391-396),
@@ -684,6 +716,7 @@ __device__ inline bool tri_mt(const double *g, const LocalRay &r, double &u, dou
     t = dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
     return true;
 }
+__device__ inline double pick3(int k, double x, double y, double z) { return k == 0 ? x : (k == 1 ? y : z); } // no runtime-indexed arrays: they go to scratch
 __device__ inline void rect_axes(int kind, int &ax, int &ua, int &va) {
     ax = kind == RTMI_PRIM_RECT_XY ? 2 : (kind == RTMI_PRIM_RECT_XZ ? 1 : 0);
     ua = kind == RTMI_PRIM_RECT_YZ ? 1 : 0;
@@ -718,10 +751,9 @@ __device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P
     } else if (kind <= RTMI_PRIM_RECT_YZ) {
         int ax, ua, va;
         rect_axes(kind, ax, ua, va);
-        const double o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
-        const double t = (g[4] - o[ax]) / d[ax];
+        const double t = (g[4] - pick3(ax, r.ox, r.oy, r.oz)) / pick3(ax, r.dx, r.dy, r.dz);
         if (t >= tmin) {
-            const double x = o[ua] + t * d[ua], y = o[va] + t * d[va];
+            const double x = pick3(ua, r.ox, r.oy, r.oz) + t * pick3(ua, r.dx, r.dy, r.dz), y = pick3(va, r.ox, r.oy, r.oz) + t * pick3(va, r.dx, r.dy, r.dz);
             if (x >= g[0] && x <= g[2] && y >= g[1] && y <= g[3]) ext_update(H, t, idx, true);
         }
     } else {
@@ -778,48 +810,15 @@ __device__ inline void scan_all_cull_ext(SceneRef sc, const Path<double> &P, dou
 __device__ inline float ext_best_hi(const ExtHit &H) { return H.t < 3.0e38 ? float_up(H.t) : 3.4028235e38f; }
 
 __device__ inline void scan_bvh_ext(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, ExtHit &H) {
-    const float ox = (float)P.ox, oy = (float)P.oy, oz = (float)P.oz;
-    const float dx = (float)P.dx, dy = (float)P.dy, dz = (float)P.dz;
-    const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-    const float ob = sc.bvh_obound;
-    const bool safe = (fabsf(ox) <= ob) && (fabsf(oy) <= ob) && (fabsf(oz) <= ob) && (dmax < 1e15f) && (dmax > 1e-15f) &&
-                      (fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= 1e-12f * dmax) && (a > 1e-30) && (a < 1e30) &&
-                      (P.time >= sc.cull_t_lo) && (P.time <= sc.cull_t_hi) && (tmin > -1e30) && (tmin < 1e30);
-    if (!safe) { scan_all_cull_ext(sc, P, a, tmin, H); return; }
+    const BvhRay r = make_bvh_ray(sc, P, a, tmin);
+    if (!r.ok) { scan_all_cull_ext(sc, P, a, tmin, H); return; }
     for (int k = 0; k < sc.n_big; ++k) ext_prim_test(sc, sc.big_idx[k], P, tmin, H);
-    int node = sc.bvh_root;
-    if (node == RTMI_BVH_EMPTY) return;
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    const float cx = -ox * ix, cy = -oy * iy, cz = -oz * iz;
-    const float tmin_lo = -float_up(-tmin);
-    const int tid = threadIdx.x, stride = blockDim.x;
-    int sp = 0;
-    const float4 *nodes = reinterpret_cast<const float4 *>(sc.bvh_nodes);
-    float best_hi = ext_best_hi(H);
-    while (node != RTMI_BVH_EMPTY) {
-        while (node >= 0 && node != RTMI_BVH_EMPTY) {
-            const float4 n0 = nodes[(size_t)node * 4], n1 = nodes[(size_t)node * 4 + 1], n2 = nodes[(size_t)node * 4 + 2], n3 = nodes[(size_t)node * 4 + 3];
-            float tl, tr;
-            const bool hl = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, cx, cy, cz, ix, iy, iz, tmin_lo, best_hi, tl);
-            const bool hr = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, cx, cy, cz, ix, iy, iz, tmin_lo, best_hi, tr);
-            const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
-            if (hl && hr) {
-                const bool left_first = tl <= tr;
-                stack[sp * stride + tid] = left_first ? cr : cl;
-                ++sp;
-                node = left_first ? cl : cr;
-            } else if (hl) node = cl;
-            else if (hr) node = cr;
-            else if (sp > 0) { --sp; node = stack[sp * stride + tid]; }
-            else node = RTMI_BVH_EMPTY;
-        }
-        if (node != RTMI_BVH_EMPTY) {
-            ext_prim_test(sc, (~node) & 0x3fffffff, P, tmin, H);
-            best_hi = ext_best_hi(H);
-            if (sp > 0) { --sp; node = stack[sp * stride + tid]; }
-            else node = RTMI_BVH_EMPTY;
-        }
-    }
+    auto leaf = [&](int code) { ext_prim_test(sc, (~code) & 0x3fffffff, P, tmin, H); };
+    auto best = [&]() { return ext_best_hi(H); };
+    if (__any(r.far ? 1 : 0)) bvh_traverse<true>(sc, stack, r, leaf, best);
+    else bvh_traverse<false>(sc, stack, r, leaf, best);
+    if (!r.time_ok) // e.g. after Isotropic.scatter, which sets the ray's time to the hit's t (shader.clj:136)
+        for (int k = 0; k < sc.n_moving_all; ++k) ext_prim_test(sc, sc.moving_all[k], P, tmin, H);
 }
 
 // hitable.clj:219-252 (MovingSphere.hit?): centre = lerp(c0, c1, (time-t0)/(t1-t0)) per ray.
@@ -920,8 +919,7 @@ __device__ inline void resolve_hit_ext(SceneRef sc, const Path<double> &P, doubl
     } else if (kind <= RTMI_PRIM_RECT_YZ) {
         int ax, ua, va;
         rect_axes(kind, ax, ua, va);
-        const double o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
-        const double x = o[ua] + t * d[ua], y = o[va] + t * d[va];
+        const double x = pick3(ua, r.ox, r.oy, r.oz) + t * pick3(ua, r.dx, r.dy, r.dz), y = pick3(va, r.ox, r.oy, r.oz) + t * pick3(va, r.dx, r.dy, r.dz);
         h.u = (x - g[0]) / (g[2] - g[0]); h.v = (y - g[1]) / (g[3] - g[1]);
         nx = ax == 0 ? 1.0 : 0.0; ny = ax == 1 ? 1.0 : 0.0; nz = ax == 2 ? 1.0 : 0.0;
     } else {

@@ -709,6 +709,16 @@ def test_cli_main_config0(tmp_path, oracle):
     assert np.abs(img.astype(int) - eq.astype(int)).max() <= 1
 
 
+def test_cli_renders_make_final(tmp_path):
+    """`lein run` as shipped renders make-final (core.clj:90): here `name nx ny ns final`"""
+    out = tmp_path / "final.ppm"
+    assert core.main([str(out), "64", "64", "4", "final"]) == 0
+    img = np.frombuffer(out.read_bytes()[len(b"P6\n64 64\n255\n"):], np.uint8).reshape(64, 64, 3)
+    assert img.mean() > 20 and img.std() > 10
+    with pytest.raises(SystemExit):
+        core.main([str(out), "8", "8", "1", "no-such-scene"])
+
+
 # ---- full BASELINE sizes: size-independent properties ----------------------------------------------------------------
 def test_full_size_properties():
     """BASELINE config 1 (800x400x64, cover scene n=11): the oracle cannot finish this in seconds, so the image is
