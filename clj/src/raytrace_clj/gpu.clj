@@ -10,13 +10,15 @@
   STATUS: written blind (no JVM/lein/JNA jar in the build container); the Python mirror in
   raytrace_clj_amd/ exercises the same C-ABI call for call and is what the tests run."
   (:require [clojure.core.matrix :as mat]
-            [raytrace-clj.scene :as scene])
+            [raytrace-clj.scene :as scene]
+            [raytrace-clj.perlin :as perlin])
   (:import [com.sun.jna Function Pointer Memory]
            [com.sun.jna.ptr PointerByReference]
            [raytrace_clj.hitable Hitlist bvh_node Sphere UVSphere MovingSphere RectXY RectXZ RectYZ Triangle
-            FlipNormals Translate RotateY Box]
-           [raytrace_clj.shader Lambertian Metal Dielectric DiffuseLight]
-           [raytrace_clj.texture Constant UVGradient Checkerboard]
+            FlipNormals Translate RotateY Box ConstantMedium]
+           [raytrace_clj.shader Lambertian Metal Dielectric DiffuseLight Isotropic]
+           [raytrace_clj.texture Constant UVGradient Checkerboard PerlinNoise PerlinTurbulence Marble
+            FlipTextureU FlipTextureV ImageMap]
            [raytrace_clj.camera PinholeCamera ThinLensCamera]))
 
 (mat/set-current-implementation :vectorz)
@@ -45,28 +47,35 @@
 (defn- v3 [v] [(mat/mget v 0) (mat/mget v 1) (mat/mget v 2)])
 
 (defprotocol GpuLeaves
-  (leaves [this chain flip]
-    "[{:leaf record :chain [[kind a b c] ...] :flip 0|1} ...] below this Hitable, in Hitlist order; chain = the
-    Translate / RotateY wrappers around the leaf, outermost first (kind 0 = translate offset.xyz, 1 = rotate-y sin cos 0)"))
+  (leaves [this chain flip in-list?]
+    "[{:leaf record :chain [[kind a b c] ...] :flip 0|1} ...] below this Hitable, in the order (and as often as) the
+    reference's descent calls hit? on them; chain = the Translate / RotateY wrappers around the leaf, outermost first
+    (kind 0 = translate offset.xyz, 1 = rotate-y sin cos 0).  A one-item make-bvh node holds the same child twice
+    (hitable.clj:113-114) and is therefore listed twice: dedup-leaves drops the repeats for the primitive table, the
+    repeats of ConstantMedium records are kept as the media call sequence."))
 
 (defn- leaf [this chain flip] [{:leaf this :chain chain :flip flip}])
 
 (extend-protocol GpuLeaves
-  Hitlist      (leaves [this c f] (mapcat #(leaves % c f) (:items this)))                       ; hitable.clj:15-26
-  bvh_node     (leaves [this c f] (concat (leaves (:left this) c f) (leaves (:right this) c f))) ; hitable.clj:97-105
-  Box          (leaves [this c f] (leaves (:sides this) c f))                                    ; hitable.clj:491-494
-  FlipNormals  (leaves [this c f] (leaves (:item this) c (bit-xor f 1)))                         ; hitable.clj:375-381
-  Translate    (leaves [this c f] (leaves (:item this) (conj c (into [0.0] (v3 (:offset this)))) f)) ; hitable.clj:391-396
-  RotateY      (leaves [this c f] (leaves (:obj this) (conj c [1.0 (:sin-theta this) (:cos-theta this) 0.0]) f)) ; :410-450
-  Sphere       (leaves [this c f] (leaf this c f))
-  UVSphere     (leaves [this c f] (leaf this c f))
-  MovingSphere (leaves [this c f] (leaf this c f))
-  RectXY       (leaves [this c f] (leaf this c f))
-  RectXZ       (leaves [this c f] (leaf this c f))
-  RectYZ       (leaves [this c f] (leaf this c f))
-  Triangle     (leaves [this c f] (leaf this c f))
-  Object       (leaves [this c f] (throw (ex-info (str (type this) " is not supported on the GPU path")
-                                                  {:unsupported-on-gpu-path (type this)}))))
+  Hitlist      (leaves [this c f l] (mapcat #(leaves % c f true) (:items this)))                        ; hitable.clj:15-26
+  bvh_node     (leaves [this c f l] (concat (leaves (:left this) c f l) (leaves (:right this) c f l)))   ; hitable.clj:97-105
+  Box          (leaves [this c f l] (leaves (:sides this) c f false))                                    ; hitable.clj:491-494
+  FlipNormals  (leaves [this c f l] (leaves (:item this) c (bit-xor f 1) l))                             ; hitable.clj:375-381
+  Translate    (leaves [this c f l] (leaves (:item this) (conj c (into [0.0] (v3 (:offset this)))) f l)) ; hitable.clj:391-396
+  RotateY      (leaves [this c f l] (leaves (:obj this) (conj c [1.0 (:sin-theta this) (:cos-theta this) 0.0]) f l)) ; :410-450
+  ConstantMedium (leaves [this c f l]                                                                    ; hitable.clj:516-541
+                   (when l (throw (ex-info "ConstantMedium inside a Hitlist is not supported on the GPU path"
+                                           {:unsupported-on-gpu-path ConstantMedium})))
+                   (leaf this c f))
+  Sphere       (leaves [this c f l] (leaf this c f))
+  UVSphere     (leaves [this c f l] (leaf this c f))
+  MovingSphere (leaves [this c f l] (leaf this c f))
+  RectXY       (leaves [this c f l] (leaf this c f))
+  RectXZ       (leaves [this c f l] (leaf this c f))
+  RectYZ       (leaves [this c f l] (leaf this c f))
+  Triangle     (leaves [this c f l] (leaf this c f))
+  Object       (leaves [this c f l] (throw (ex-info (str (type this) " is not supported on the GPU path")
+                                                    {:unsupported-on-gpu-path (type this)}))))
 
 (defn- dedup-leaves
   "a one-item make-bvh stores the same child twice (hitable.clj:113-114): drop repeats of the same record under the
@@ -85,10 +94,22 @@
           (swap! table update :rows conj row)
           id))))
 
+(def ^:private images (atom []))   ; BufferedImages met while flattening, in ImageMap index order
+
+(defn- pad12 [xs] (take 12 (concat (map double xs) (repeat 0.0))))
+
 (defn- tex-row [textures t]
   (condp instance? t
     Constant     {:kind 0 :param (concat (v3 (:color t)) (repeat 9 0.0)) :child [-1 -1]}
     UVGradient   {:kind 1 :param (mapcat v3 [(:co t) (:cu t) (:cv t) (:cuv t)]) :child [-1 -1]}
+    PerlinNoise      {:kind 3 :param (pad12 [(:scale t)]) :child [-1 -1]}                              ; texture.clj:60
+    PerlinTurbulence {:kind 4 :param (pad12 [(:scale t) (:depth t)]) :child [-1 -1]}                   ; texture.clj:74
+    Marble           {:kind 5 :param (pad12 [(:scale t) (:depth t)]) :child [-1 -1]}                   ; texture.clj:88
+    FlipTextureU     {:kind 6 :param (pad12 []) :child [(intern! textures (:tex t) (partial tex-row textures)) -1]} ; :103
+    FlipTextureV     {:kind 7 :param (pad12 []) :child [(intern! textures (:tex t) (partial tex-row textures)) -1]} ; :113
+    ImageMap         (let [id (count @images)]                                                         ; texture.clj:126
+                       (swap! images conj (:image t))
+                       {:kind 8 :param (pad12 [id]) :child [-1 -1]})
     Checkerboard (let [c0 (intern! textures (:tex0 t) (partial tex-row textures))
                        c1 (intern! textures (:tex1 t) (partial tex-row textures))]
                    {:kind 2 :param (cons (double (:scale t)) (repeat 11 0.0)) :child [c0 c1]})
@@ -101,6 +122,7 @@
       Metal        {:kind 1 :tex (tex (:albedo m)) :param (double (:fuzz m))}
       Dielectric   {:kind 2 :tex -1 :param (double (:ri m))}
       DiffuseLight {:kind 3 :tex (tex (:tex m)) :param 0.0}
+      Isotropic    {:kind 4 :tex (tex (:albedo m)) :param 0.0}                    ; shader.clj:129, a medium's phase function
       (throw (ex-info (str (type m) " is not supported on the GPU path") {:unsupported-on-gpu-path (type m)})))))
 
 (defn- pad9 [xs] (take 9 (concat (map double xs) (repeat 0.0))))
@@ -114,7 +136,8 @@
     RectXY       {:kind 3 :geom (pad9 [(:x0 o) (:y0 o) (:x1 o) (:y1 o) (:k o)])}   ; hitable.clj:269
     RectXZ       {:kind 4 :geom (pad9 [(:x0 o) (:z0 o) (:x1 o) (:z1 o) (:k o)])}   ; hitable.clj:301
     RectYZ       {:kind 5 :geom (pad9 [(:y0 o) (:z0 o) (:y1 o) (:z1 o) (:k o)])}   ; hitable.clj:333
-    Triangle     {:kind 6 :geom (concat (v3 (:v0 o)) (v3 (:v1 o)) (v3 (:v2 o)))})) ; hitable.clj:548
+    Triangle     {:kind 6 :geom (concat (v3 (:v0 o)) (v3 (:v1 o)) (v3 (:v2 o)))}   ; hitable.clj:548
+    ConstantMedium {:kind 7 :geom (pad9 [(:density o)])}))  ; hitable.clj:516; boundary range patched in by flatten-scene
 
 (defn- camera-row [c]
   (condp instance? c
@@ -126,12 +149,39 @@
 (defn flatten-scene
   "{:camera c :world w} -> the flat arrays of include/rtmi.h (as Clojure primitive arrays)"
   [{:keys [camera world]}]
-  (let [entries   (dedup-leaves (leaves world [] 0))
+  (reset! images [])
+  (let [called    (vec (leaves world [] 0 false))          ; hit? invocation order, repeats included
+        world-es  (dedup-leaves called)
+        key-of    (fn [e] [(System/identityHashCode (:leaf e)) (:chain e) (:flip e)])
+        index-of  (zipmap (map key-of world-es) (range))
+        media-calls (mapv #(index-of (key-of %)) (filter #(instance? ConstantMedium (:leaf %)) called))
+        ;; every medium's boundary is flattened on its own and appended AFTER the world (kind | 16)
+        bounds    (reduce (fn [acc [i e]]
+                            (if (instance? ConstantMedium (:leaf e))
+                              (let [b (dedup-leaves (leaves (:boundary (:leaf e)) (:chain e) (:flip e) false))]
+                                (-> acc
+                                    (assoc-in [:range i] [(+ (count world-es) (count (:prims acc))) (count b)])
+                                    (update :prims into b)))
+                              acc))
+                          {:range {} :prims []}
+                          (map-indexed vector world-es))
+        n-world   (count world-es)
+        entries   (into (vec world-es) (:prims bounds))
         prims     (mapv :leaf entries)
+        material-of (fn [o] (if (instance? ConstantMedium o) (:phase-fn o) (:material o)))
         textures  (atom {:ids (java.util.IdentityHashMap.) :rows []})
         materials (atom {:ids (java.util.IdentityHashMap.) :rows []})
-        prim-mat  (mapv #(intern! materials (:material %) (partial mat-row textures)) prims)
-        prows     (mapv prim-row prims)
+        prim-mat  (mapv #(intern! materials (material-of %) (partial mat-row textures)) prims)
+        prows     (vec (map-indexed
+                        (fn [i o]
+                          (let [row (prim-row o)]
+                            (cond
+                              (instance? ConstantMedium o)
+                              (let [[fb nb] (get-in bounds [:range i])]
+                                (assoc row :geom (pad9 [(:density o) fb nb])))
+                              (>= i n-world) (update row :kind bit-or 16)
+                              :else row)))
+                        prims))
         ;; transform table: every distinct chain once; per primitive [first count]
         chains    (vec (distinct (remove empty? (map :chain entries))))
         starts    (reductions + 0 (map count chains))
@@ -158,7 +208,10 @@
      :prim-xform (int-array (mapcat (fn [e] (if (empty? (:chain e)) [0 0] [(chain-at (:chain e)) (count (:chain e))])) entries))
      :n-xforms   (count xforms)
      :xform-kind  (int-array (map #(int (first %)) xforms))
-     :xform-param (double-array (mapcat rest xforms))}))
+     :xform-param (double-array (mapcat rest xforms))
+     :media-calls (int-array media-calls)
+     :uses-perlin (boolean (some #(#{3 4 5} (:kind %)) trows))
+     :images      @images}))
 
 ;;; ---------------------------------------------------------------------------------------------
 ;;; render: replaces (dorun (cp/upmap ...)) of core.clj:100-108
@@ -184,6 +237,24 @@
                        (int (:n-tex f)) (:tex-kind f) (:tex-param f) (:tex-child f)
                        (:cam-kind f) (:cam f)
                        (:prim-flip f) (:prim-xform f) (int (:n-xforms f)) (:xform-kind f) (:xform-param f) scn))
+      ;; the namespace-level Perlin tables of the running JVM (perlin.clj:6-17)
+      (when (:uses-perlin f)
+        (check (call-int "rtmi_scene_set_perlin" (.getValue scn)
+                         (double-array (mapcat v3 perlin/random-vectors))
+                         (int-array (concat perlin/perm-x perlin/perm-y perlin/perm-z)))))
+      ;; ImageMap pixels: rows top-down, RGB (imagez get-pixel = BufferedImage.getRGB, texture.clj:76)
+      (when (seq (:images f))
+        (let [imgs (:images f)
+              wh   (int-array (mapcat (fn [^java.awt.image.BufferedImage im] [(.getWidth im) (.getHeight im)]) imgs))
+              rgb  (byte-array (mapcat (fn [^java.awt.image.BufferedImage im]
+                                         (for [y (range (.getHeight im)) x (range (.getWidth im))
+                                               :let [p (.getRGB im (int x) (int y))]
+                                               sh [16 8 0]]
+                                           (unchecked-byte (bit-and 0xff (bit-shift-right p sh)))))
+                                       imgs))]
+          (check (call-int "rtmi_scene_set_images" (.getValue scn) (int (count imgs)) wh rgb))))
+      (when (pos? (alength ^ints (:media-calls f)))
+        (check (call-int "rtmi_scene_set_media_calls" (.getValue scn) (int (alength ^ints (:media-calls f))) (:media-calls f))))
       (try
         (check (call-int "rtmi_render" (.getValue scn) (int nx) (int ny) (int ns) (int depth) (long seed) (int precision)
                          (int 0) (int 0) (int nx) (int ny) lin rgb cnt))
@@ -201,13 +272,16 @@
 (defn -main
   "lein run name nx ny ns -- same positional arguments as raytrace-clj.core/-main (core.clj:73-80);
   renders the cover scene (the commented-out line core.clj:89)."
-  [& [name ix iy is]]
+  [& [name ix iy is which]]
   (let [tstart   (System/currentTimeMillis)
         filename (or name "render.ppm")
         nx (if ix (Integer/parseUnsignedInt ix) 200)
         ny (if iy (Integer/parseUnsignedInt iy) 100)
         nr (if is (Integer/parseUnsignedInt is) 100)
-        {:keys [rgb8 total-rays total-pixels]} (render (scene/make-random-scene nx ny 11 true) nx ny nr)
+        sc (if (= which "final")
+             (scene/make-final nx ny)                 ; core.clj:90 (needs earth.png in the working directory)
+             (scene/make-random-scene nx ny 11 true)) ; core.clj:89
+        {:keys [rgb8 total-rays total-pixels]} (render sc nx ny nr)
         elapsed (/ (- (System/currentTimeMillis) tstart) 1000.0)]
     (println (format "%.2fs, %d%%, ETA %.2fs" elapsed 100 0.0))      ; display.clj:20-24
     (println "total-rays" total-rays "total-pixels" total-pixels)    ; metrics.clj:8-9
