@@ -340,6 +340,48 @@ def test_bvh_accel_is_bit_identical(oracle, cover11, cover11_moving):
         ctx.close()
 
 
+def test_bvh_far_origins_and_out_of_shutter_times(oracle, cover11_moving):
+    """rays the host-side box inflation does not cover take their own slab slack (origins up to 10^6 scene radii away), and
+    rays whose time lies outside the camera's shutter interval test every MovingSphere exhaustively: both must stay exact"""
+    f = fl.flatten(cover11_moving)
+    rng = np.random.default_rng(12)
+    n = 30000
+    target = rng.normal(0, 4, (n, 3)) * np.array([1, 0.1, 1]) + np.array([0, 0.3, 0])
+    dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    dist = 10.0 ** rng.uniform(0.5, 9, (n, 1))
+    o = target - dirs * dist
+    d = dirs * rng.choice([1.0, 1e-3, 50.0], (n, 1))
+    times = rng.choice([0.5, -3.0, 7.25, 1.0, 0.0, 55.0], (n, 1))
+    rays = np.concatenate([o, d, times], axis=1)
+    exp = oracle.probe_hit(f, rays)
+    ctx = core.Context(0)
+    ds = core.DeviceScene(f, ctx=ctx)
+    for accel in (1, 0):
+        ctx.set_option("accel", accel)
+        got = ds.probe_hit(rays)
+        assert np.array_equal(got[:, :9], exp[:, :9]), accel
+    ds.close(); ctx.close()
+    small = exp[:, 1] != np.flatnonzero(f.prim_geom[:, 3] == 1000)[0]
+    assert (exp[:, 0] == 1).all() and small.mean() > 0.2  # the far rays really do reach the small (incl. moving) spheres
+
+
+def test_bench_json_schema():
+    """bench.py prints ONE JSON line with the contract's keys (run as the driver runs it, tiny step counts)"""
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["value"] > 100 and "workload" in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert d["other_accel"]["accel"] == "flat" and d["other_accel"]["value"] > 100
+
+
 def test_bvh_full_size_image_identical():
     nx, ny, ns = 800, 400, 16
     sc = r.scene.make_random_scene(nx, ny, 11, True)
