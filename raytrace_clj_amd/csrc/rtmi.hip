@@ -35,6 +35,20 @@ using namespace rtmi;
 namespace {
 
 constexpr int kBlock = 256;
+// Diagnostic build only (make stamps -> librtmi_stamps.so): s_memtime around the phases of a loop trip, summed per wave and
+// added to g_stamps[phase], printed to stderr after every render.  Never defined in the shipped library.
+#ifdef RTMI_STAMPS
+#define RTMI_STAMP_DECL unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = stamp_now(); const unsigned long long st_wg0 = real_now();
+#define RTMI_STAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = stamp_now(); st_acc[k] += n_ - st_t; st_t = n_; __builtin_amdgcn_sched_barrier(0); }
+__device__ unsigned long long g_wg_t[2][4096]; // s_memrealtime (100 MHz) at workgroup start / end
+__device__ inline unsigned long long real_now() { unsigned long long t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }
+#define RTMI_STAMP_FLUSH(cnt) if (lane == 0) { for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_stamps[k_], st_acc[k_]); } \
+    __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4096) { g_wg_t[0][blockIdx.x] = st_wg0; g_wg_t[1][blockIdx.x] = real_now(); }
+#else
+#define RTMI_STAMP_DECL
+#define RTMI_STAMP(k)
+#define RTMI_STAMP_FLUSH(cnt)
+#endif
 #ifndef RTMI_MIN_WAVES
 #define RTMI_MIN_WAVES 4
 #endif
@@ -50,7 +64,10 @@ struct TraceParams {
     u64 *counters;         // [0] += ray segments (metrics total-rays, core.clj:24)
     int prims_per_tile;    // static spheres per LDS tile
     int n_ptiles;          // number of LDS tiles the static spheres are cut into
+    unsigned *queue;       // work queue head of this pass (zeroed before the launch): next unclaimed work item
+    unsigned total_items;  // n_local_tiles * s_count * 64
 };
+constexpr unsigned kQueueBlock = 256; // work items a wave claims per queue access: 4 chunks = one tile x 4 consecutive samples
 
 template <typename R> __device__ inline const R *stat4_of(SceneRef sc);
 // Stage static spheres [first, first+count) into LDS as {cx, cy, cz, r*r} (hitable.clj:188: (* radius radius)).
@@ -169,65 +186,69 @@ __global__ void __launch_bounds__(kBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr 
     SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Prim4<R> *lds = reinterpret_cast<Prim4<R> *>(smem);
-    unsigned *wg_next = reinterpret_cast<unsigned *>(smem + (VARIANT == SCAN_BVH ? (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) : (size_t)tp.prims_per_tile * sizeof(Prim4<R>)));
-
     const int lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) *wg_next = 0u;
     if (!MULTI && VARIANT < SCAN_SGPR) stage_prims<R>(sc, lds, 0, sc.n_static);
     __syncthreads();
 
-    // This workgroup's work list: chunks blockIdx.x, blockIdx.x + gridDim.x, ...; a chunk is one 8x8 pixel
-    // tile x one sample index (64 work items); chunk c -> (local tile c / s_count, sample s_begin + c % s_count).
-    const long long total_chunks = (long long)tp.n_local_tiles * tp.s_count;
-    const long long my_chunks = total_chunks > blockIdx.x ? (total_chunks - blockIdx.x - 1) / gridDim.x + 1 : 0;
-    const unsigned total_m = (unsigned)min(my_chunks * 64, (long long)0xffffff00u);
-
+    // Work distribution: one queue for the whole launch.  A work item is one sample of one pixel; item m belongs to chunk
+    // m / 64 = (local tile m / (64 s_count), sample s_begin + (m / 64) % s_count), pixel m % 64 of that 8x8 tile.  Each WAVE
+    // claims kQueueBlock consecutive items at a time with one global atomic and hands them to its dead lanes; no wave idles
+    // while the queue holds work, whatever the other waves' paths do.  (Which wave renders an item never affects the result:
+    // the RNG stream is a function of (seed, pixel, sample) only.)
+    const unsigned total_items = tp.total_items;
+    unsigned w_cur = 0, w_end = 0; // this wave's claimed range [w_cur, w_end): wave-uniform
     Path<R> P;
     P.ox = P.oy = P.oz = P.dx = P.dy = P.dz = P.time = R(0);
     P.ar = P.ag = P.ab = P.cr = P.cg = P.cb = R(0);
     seed_stream(P, 0ull, 0u); P.depth = 0;
     bool alive = false;
-    bool exhausted = (total_m == 0);
+    bool exhausted = (total_items == 0);
     size_t out_idx = 0;
     unsigned nrays = 0;
     const R tmin = R(0.001), tmax = Real<R>::tmax();
 
+    RTMI_STAMP_DECL
     for (;;) {
+        RTMI_STAMP(5) // loop overhead / tail
         // ---- refill dead lanes: ballot -> popcount prefix -> one LDS atomic per wave -------------------
-        while (!exhausted) {
+        while (!exhausted) { // every lane of the wave takes part: the loop conditions are wave-uniform
             const u64 dead = __ballot(!alive);
             if (dead == 0) break;
-            const int cnt = __popcll(dead);
-            const int leader = __ffsll((long long)dead) - 1;
-            unsigned base = 0;
-            if (lane == leader) base = atomicAdd(wg_next, (unsigned)cnt);
-            base = __shfl(base, leader);
-            if (base >= total_m) { exhausted = true; break; }
-            if (base + (unsigned)cnt >= total_m) exhausted = true;
-            if (!alive) {
-                const unsigned m = base + (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
-                if (m < total_m) {
-                    const long long chunk = (long long)blockIdx.x + (long long)(m >> 6) * gridDim.x;
-                    const int l = (int)(m & 63u);
-                    const int tile_local = (int)(chunk / tp.s_count);
-                    const int s = tp.s_begin + (int)(chunk - (long long)tile_local * tp.s_count);
-                    const int gtile = tp.tile_ids[tile_local];
-                    const int x = (gtile % tp.tiles_x) * RTMI_TILE + (l & 7);
-                    const int y = (gtile / tp.tiles_x) * RTMI_TILE + (l >> 3);
-                    if (x < tp.nx && y < tp.ny) {
-                        start_sample<R>(sc, tp, x, tp.ny - 1 - y, s, P); // j = ny-1-y (core.clj:105)
-                        out_idx = ((size_t)chunk * 64 + (size_t)l) * 3;
-                        alive = true;
-                    }
+            if (w_cur == w_end) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(tp.queue, kQueueBlock);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= total_items) { exhausted = true; break; }
+                w_cur = base;
+                w_end = min(base + kQueueBlock, total_items);
+            }
+            const unsigned avail = w_end - w_cur;
+            const unsigned rank = (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
+            if (!alive && rank < avail) {
+                const unsigned m = w_cur + rank;
+                const unsigned chunk = m >> 6;
+                const int l = (int)(m & 63u);
+                const int tile_local = (int)(chunk / (unsigned)tp.s_count);
+                const int s = tp.s_begin + (int)(chunk - (unsigned)tile_local * (unsigned)tp.s_count);
+                const int gtile = tp.tile_ids[tile_local];
+                const int x = (gtile % tp.tiles_x) * RTMI_TILE + (l & 7);
+                const int y = (gtile / tp.tiles_x) * RTMI_TILE + (l >> 3);
+                if (x < tp.nx && y < tp.ny) {
+                    start_sample<R>(sc, tp, x, tp.ny - 1 - y, s, P); // j = ny-1-y (core.clj:105)
+                    out_idx = (size_t)m * 3;
+                    alive = true;
                 }
             }
+            w_cur += min((unsigned)__popcll(dead), avail);
         }
         if (MULTI) { if (!__syncthreads_or(alive ? 1 : 0)) break; }
         else { if (!__any(alive ? 1 : 0)) break; }
+        RTMI_STAMP(0) // refill
 
         // ---- one iteration of `color` for every live lane ---------------------------------------------
         R best_t; int best_i;
         intersect_world<R, MULTI, VARIANT, EXT>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i);
+        RTMI_STAMP(1) // intersection
         if (alive) {
             ++nrays;
             if (!shade_segment<R, EXT>(sc, P, best_t, best_i, nullptr)) {
@@ -236,7 +257,9 @@ __global__ void __launch_bounds__(kBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr 
                 alive = false;
             }
         }
+        RTMI_STAMP(2) // shading
     }
+    RTMI_STAMP_FLUSH(tp.counters)
     // total-rays: wave reduction, one atomic per wave
     unsigned n = nrays;
     for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
@@ -565,16 +588,17 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
     if (rc) return rc;
     if (d_counters) HIP_TRY(hipMemsetAsync(d_counters, 0, 2 * sizeof(u64), st));
     if (n_local == 0) return RTMI_OK;
-    rc = c->counters.ensure(2 * sizeof(u64));
+    rc = c->counters.ensure(4 * sizeof(u64)); // [0..1] the metrics when the caller passes no buffer, [2] the work-queue head
     if (rc) return rc;
     u64 *cnt = d_counters ? reinterpret_cast<u64 *>(d_counters) : reinterpret_cast<u64 *>(c->counters.p);
+    unsigned *queue = reinterpret_cast<unsigned *>(reinterpret_cast<u64 *>(c->counters.p) + 2);
 
     // sample-buffer passes: samples [s_begin, s_begin+s_count) of every local pixel per pass
     const size_t per_sample = (size_t)n_local * 64 * 3 * sizeof(R);
     int s_per_pass = (int)std::max<int64_t>(1, std::min<int64_t>(ns, c->workspace_bytes / (int64_t)per_sample));
-    const int grid_trace = std::max(1, c->cus * c->blocks_per_cu);
-    // a workgroup's work list is indexed with 32 bits: (chunks per workgroup) * 64 must stay below 2^32
-    while (s_per_pass > 1 && ((long long)n_local * s_per_pass / grid_trace + 1) * 64 >= 0xffffff00ll) s_per_pass /= 2;
+    // the work queue is indexed with 32 bits: items per pass (+ one claim per wave past the end) must stay below 2^32
+    while (s_per_pass > 1 && (long long)n_local * s_per_pass * 64 >= 0xf0000000ll) s_per_pass /= 2;
+    if ((long long)n_local * s_per_pass * 64 >= 0xf0000000ll) return fail(RTMI_E_ARG, "frame too large for one pass: %d tiles per rank", n_local);
     rc = c->samples.ensure(per_sample * (size_t)s_per_pass);
     if (rc) return rc;
     if (s_per_pass < ns) {
@@ -599,31 +623,28 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             if (rc) return rc;
             HIP_TRY(hipEventRecord(e0, st));
         }
+        tp.queue = queue; tp.total_items = (unsigned)((long long)n_local * s_count * 64);
+        HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned), st));
         const int variant = c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant;
+        void (*kern)(ScenePtr, TraceParams) = nullptr;
+        size_t dyn_lds = 0;
+        const size_t bvh_lds = (size_t)RTMI_BVH_STACK * kBlock * sizeof(int);
         if (s->dev.has_ext) { // section 8(f3) scenes: FP64 kernels with the mixed-kind intersectors
-            if (variant == SCAN_BVH)
-                hipLaunchKernelGGL((trace_kernel<double, false, SCAN_BVH, true>), dim3(grid_trace), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, st, s->d_dev, tp);
-            else
-                hipLaunchKernelGGL((trace_kernel<double, false, SCAN_SGPR_CULL, true>), dim3(grid_trace), dim3(kBlock), 16, st, s->d_dev, tp);
+            if (variant == SCAN_BVH) { kern = trace_kernel<double, false, SCAN_BVH, true>; dyn_lds = bvh_lds; }
+            else kern = trace_kernel<double, false, SCAN_SGPR_CULL, true>;
         } else
         switch (variant) {
-        case SCAN_BVH:
-            hipLaunchKernelGGL((trace_kernel<R, false, SCAN_BVH>), dim3(grid_trace), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, st, s->d_dev, tp);
-            break;
-        case SCAN_SGPR_CULL:
-            hipLaunchKernelGGL((trace_kernel<R, false, SCAN_SGPR_CULL>), dim3(grid_trace), dim3(kBlock), 16, st, s->d_dev, tp);
-            break;
-        case SCAN_SGPR:
-            hipLaunchKernelGGL((trace_kernel<R, false, SCAN_SGPR>), dim3(grid_trace), dim3(kBlock), 16, st, s->d_dev, tp);
-            break;
-        case SCAN_LDS_PIPE:
-            if (multi) hipLaunchKernelGGL((trace_kernel<R, true, SCAN_LDS_PIPE>), dim3(grid_trace), dim3(kBlock), lds_bytes, st, s->d_dev, tp);
-            else hipLaunchKernelGGL((trace_kernel<R, false, SCAN_LDS_PIPE>), dim3(grid_trace), dim3(kBlock), lds_bytes, st, s->d_dev, tp);
-            break;
-        default:
-            if (multi) hipLaunchKernelGGL((trace_kernel<R, true, SCAN_LDS_LITERAL>), dim3(grid_trace), dim3(kBlock), lds_bytes, st, s->d_dev, tp);
-            else hipLaunchKernelGGL((trace_kernel<R, false, SCAN_LDS_LITERAL>), dim3(grid_trace), dim3(kBlock), lds_bytes, st, s->d_dev, tp);
+        case SCAN_BVH: kern = trace_kernel<R, false, SCAN_BVH>; dyn_lds = bvh_lds; break;
+        case SCAN_SGPR_CULL: kern = trace_kernel<R, false, SCAN_SGPR_CULL>; break;
+        case SCAN_SGPR: kern = trace_kernel<R, false, SCAN_SGPR>; break;
+        case SCAN_LDS_PIPE: kern = multi ? trace_kernel<R, true, SCAN_LDS_PIPE> : trace_kernel<R, false, SCAN_LDS_PIPE>; dyn_lds = lds_bytes; break;
+        default: kern = multi ? trace_kernel<R, true, SCAN_LDS_LITERAL> : trace_kernel<R, false, SCAN_LDS_LITERAL>; dyn_lds = lds_bytes;
         }
+        // persistent launch: as many workgroups as stay resident (at most blocks_per_cu per CU); the queue feeds them
+        int resident = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, kBlock, dyn_lds));
+        const int grid_trace = std::max(1, c->cus * std::max(1, std::min(c->blocks_per_cu, resident)));
+        hipLaunchKernelGGL(kern, dim3(grid_trace), dim3(kBlock), dyn_lds, st, s->d_dev, tp);
         HIP_TRY(hipGetLastError());
         if (e1) HIP_TRY(hipEventRecord(e1, st));
         const long long npx = (long long)n_local * 64;
@@ -633,6 +654,33 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
                            n_local, s_begin, s_count, ns, d_counters ? cnt : nullptr, (u64)c->tile_valid_pixels);
         HIP_TRY(hipGetLastError());
     }
+#ifdef RTMI_STAMPS
+    {
+        const int grid_trace_dbg = std::max(1, c->cus * c->blocks_per_cu);
+        HIP_TRY(hipStreamSynchronize(st));
+        unsigned long long h[8] = {0}, z[8] = {0};
+        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)));
+        unsigned long long h2[8] = {0};
+        HIP_TRY(hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_stamps2), sizeof(h2)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps2), z, sizeof(z)));
+        fprintf(stderr, "[stamps] bvh: inner ticks %.3g leaf ticks %.3g | inner trips %llu (lanes/trip %.1f) leaf trips %llu (lanes/trip %.1f) calls %llu\n",
+                (double)h2[0], (double)h2[1], h2[2], (double)h2[3] / (double)(h2[2] ? h2[2] : 1), h2[4], (double)h2[5] / (double)(h2[4] ? h2[4] : 1), h2[6]);
+        {
+            static unsigned long long wt[2][4096];
+            HIP_TRY(hipMemcpyFromSymbol(wt, HIP_SYMBOL(g_wg_t), sizeof(wt)));
+            const int g = std::min(4096, grid_trace_dbg);
+            unsigned long long t0 = ~0ull; for (int k = 0; k < g; ++k) t0 = std::min(t0, wt[0][k]);
+            std::vector<double> e(g), b(g); for (int k = 0; k < g; ++k) { e[k] = (wt[1][k] - t0) * 1e-5; b[k] = (wt[0][k] - t0) * 1e-5; }
+            std::sort(e.begin(), e.end()); std::sort(b.begin(), b.end());
+            fprintf(stderr, "[stamps] workgroup start (ms after first): median %.3f max %.3f | end: min %.3f p10 %.3f median %.3f p90 %.3f max %.3f (last pass, %d workgroups)\n",
+                    b[g / 2], b[g - 1], e[0], e[g / 10], e[g / 2], e[g * 9 / 10], e[g - 1], g);
+        }
+        double tot = 0; for (int k = 0; k < 6; ++k) tot += (double)h[k];
+        fprintf(stderr, "[stamps] refill %.1f%% intersect %.1f%% shade %.1f%% (3: %.1f%% 4: %.1f%%) loop %.1f%%  total %.3g wave-ticks\n", 100 * h[0] / tot,
+                100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, tot);
+    }
+#endif
     return RTMI_OK;
 }
 

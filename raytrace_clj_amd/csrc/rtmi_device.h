@@ -521,7 +521,9 @@ __device__ inline void scan_all_cull(SceneRef sc, const Path<double> &P, double 
 // Closest hit is order independent: candidate(prim) = first root if > t-min else second root (hitable.clj:192-207 with the
 // running t-max of hitable.clj:20 only ever rejecting non-minimal candidates); ties -> lowest Hitlist index (first wins).
 #define RTMI_BVH_EMPTY 0x7fffffff
+#ifndef RTMI_BVH_STACK
 #define RTMI_BVH_STACK 32
+#endif
 
 __device__ inline void sphere_roots_any_order(double bq, double cq, double disc, double a, double tmin, bool behind_ok, double &best_t, int &best_i, int idx) {
     if (behind_ok && bq > 0.0 && cq > 0.0) return;
@@ -608,6 +610,14 @@ __device__ inline BvhRay make_bvh_ray(SceneRef sc, const Path<double> &P, double
 // leaf run the exact FP64 test together -- the expensive FP64 code is not interleaved with box tests.  Stack: LDS, one
 // column per thread (stack[level * blockDim.x + tid]: conflict-free).  leaf(code) runs the exact test, best() returns the
 // current float upper bound of the closest t.
+#ifdef RTMI_STAMPS // diagnostic build only (make stamps)
+__device__ unsigned long long g_stamps[8], g_stamps2[8];
+__device__ inline unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#endif
 template <bool FAR, typename Leaf, typename BestHi>
 __device__ inline void bvh_traverse(SceneRef sc, int *stack, const BvhRay &r, Leaf leaf, BestHi best) {
     int node = sc.bvh_root;
@@ -616,8 +626,19 @@ __device__ inline void bvh_traverse(SceneRef sc, int *stack, const BvhRay &r, Le
     int sp = 0;
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.bvh_nodes);
     float best_hi = best();
+#ifdef RTMI_STAMPS_BVH
+    __shared__ unsigned st_w[4][4]; // per wave: inner trips, inner lane-trips, leaf trips, leaf lane-trips (written by one lane at a time)
+    const int st_wave = threadIdx.x >> 6, st_lane = threadIdx.x & 63;
+    if (st_lane == __ffsll((long long)__ballot(1)) - 1) { st_w[st_wave][0] = 0; st_w[st_wave][1] = 0; st_w[st_wave][2] = 0; st_w[st_wave][3] = 0; }
+    __shared__ unsigned long long st_c[4][2]; // per wave: ticks in the inner loop, ticks in the leaf tests
+    if (st_lane == __ffsll((long long)__ballot(1)) - 1) { st_c[st_wave][0] = 0; st_c[st_wave][1] = 0; }
+    unsigned long long s_t = stamp_now();
+#endif
     while (node != RTMI_BVH_EMPTY) {
         while (node >= 0 && node != RTMI_BVH_EMPTY) { // inner node: both child boxes come with it (one 64-byte record)
+#ifdef RTMI_STAMPS_BVH
+            { const unsigned long long m_ = __ballot(1); if (st_lane == __ffsll((long long)m_) - 1) { st_w[st_wave][0] += 1; st_w[st_wave][1] += __popcll(m_); } }
+#endif
             const float4 n0 = nodes[(size_t)node * 4], n1 = nodes[(size_t)node * 4 + 1], n2 = nodes[(size_t)node * 4 + 2], n3 = nodes[(size_t)node * 4 + 3];
             float tl, tr;
             const bool hl = box_hit<FAR>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r.cx, r.cy, r.cz, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tmin_lo, best_hi, tl);
@@ -633,13 +654,27 @@ __device__ inline void bvh_traverse(SceneRef sc, int *stack, const BvhRay &r, Le
             else if (sp > 0) { --sp; node = stack[sp * stride + tid]; }
             else node = RTMI_BVH_EMPTY;
         }
+#ifdef RTMI_STAMPS_BVH
+        { const unsigned long long n_ = stamp_now(); if (st_lane == __ffsll((long long)__ballot(1)) - 1) st_c[st_wave][0] += n_ - s_t; s_t = n_; }
+        if (node != RTMI_BVH_EMPTY) { const unsigned long long m_ = __ballot(1); if (st_lane == __ffsll((long long)m_) - 1) { st_w[st_wave][2] += 1; st_w[st_wave][3] += __popcll(m_); } }
+#endif
         if (node != RTMI_BVH_EMPTY) { // leaf: one primitive, exact FP64 test
             leaf(node);
             best_hi = best();
             if (sp > 0) { --sp; node = stack[sp * stride + tid]; }
             else node = RTMI_BVH_EMPTY;
         }
+#ifdef RTMI_STAMPS_BVH
+        { const unsigned long long n_ = stamp_now(); if (st_lane == __ffsll((long long)__ballot(1)) - 1) st_c[st_wave][1] += n_ - s_t; s_t = n_; }
+#endif
     }
+#ifdef RTMI_STAMPS_BVH
+    if (st_lane == __ffsll((long long)__ballot(1)) - 1) { // s_in / s_lf are wave times (s_memtime is scalar): one lane reports
+        atomicAdd(&g_stamps2[0], st_c[st_wave][0]); atomicAdd(&g_stamps2[1], st_c[st_wave][1]); atomicAdd(&g_stamps2[2], (unsigned long long)st_w[st_wave][0]);
+        atomicAdd(&g_stamps2[3], (unsigned long long)st_w[st_wave][1]); atomicAdd(&g_stamps2[4], (unsigned long long)st_w[st_wave][2]);
+        atomicAdd(&g_stamps2[5], (unsigned long long)st_w[st_wave][3]); atomicAdd(&g_stamps2[6], 1ull);
+    }
+#endif
 }
 
 __device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, double &best_t, int &best_i) {
