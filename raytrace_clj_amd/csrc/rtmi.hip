@@ -67,7 +67,10 @@ struct TraceParams {
     unsigned *queue;       // work queue head of this pass (zeroed before the launch): next unclaimed work item
     unsigned total_items;  // n_local_tiles * s_count * 64
 };
-constexpr unsigned kQueueBlock = 256; // work items a wave claims per queue access: 4 chunks = one tile x 4 consecutive samples
+#ifndef RTMI_QUEUE_BLOCK
+#define RTMI_QUEUE_BLOCK 256
+#endif
+constexpr unsigned kQueueBlock = RTMI_QUEUE_BLOCK; // work items a wave claims per queue access: 4 chunks = one tile x 4 consecutive samples
 
 template <typename R> __device__ inline const R *stat4_of(SceneRef sc);
 // Stage static spheres [first, first+count) into LDS as {cx, cy, cz, r*r} (hitable.clj:188: (* radius radius)).
