@@ -11,7 +11,9 @@
   raytrace_clj_amd/ exercises the same C-ABI call for call and is what the tests run."
   (:require [clojure.core.matrix :as mat]
             [raytrace-clj.scene :as scene]
-            [raytrace-clj.perlin :as perlin])
+            [raytrace-clj.perlin :as perlin]
+            [mikera.image.core :refer [new-image set-pixel save]]
+            [mikera.image.colours :refer [rgb-from-components]])
   (:import [com.sun.jna Function Pointer Memory]
            [com.sun.jna.ptr PointerByReference]
            [raytrace_clj.hitable Hitlist bvh_node Sphere UVSphere MovingSphere RectXY RectXZ RectYZ Triangle
@@ -269,12 +271,24 @@
     (.write o (.getBytes (format "P6\n%d %d\n255\n" nx ny)))
     (.write o rgb8)))
 
+(defn save-image
+  "what core.clj:104-106,112 does with the pixels: an imagez image saved by extension (PNG by default, core.clj:76).
+  rgb8 is row-major with row 0 = top, so no flip is needed here."
+  [filename ^bytes rgb8 nx ny]
+  (let [image (new-image nx ny)]
+    (doseq [j (range ny) i (range nx)]
+      (let [o (* 3 (+ i (* j nx)))]
+        (set-pixel image i j (rgb-from-components (bit-and 0xff (aget rgb8 o))
+                                                  (bit-and 0xff (aget rgb8 (+ o 1)))
+                                                  (bit-and 0xff (aget rgb8 (+ o 2)))))))
+    (save image filename)))
+
 (defn -main
   "lein run name nx ny ns -- same positional arguments as raytrace-clj.core/-main (core.clj:73-80);
   renders the cover scene (the commented-out line core.clj:89)."
   [& [name ix iy is which]]
   (let [tstart   (System/currentTimeMillis)
-        filename (or name "render.ppm")
+        filename (or name "render.png")
         nx (if ix (Integer/parseUnsignedInt ix) 200)
         ny (if iy (Integer/parseUnsignedInt iy) 100)
         nr (if is (Integer/parseUnsignedInt is) 100)
@@ -285,5 +299,7 @@
         elapsed (/ (- (System/currentTimeMillis) tstart) 1000.0)]
     (println (format "%.2fs, %d%%, ETA %.2fs" elapsed 100 0.0))      ; display.clj:20-24
     (println "total-rays" total-rays "total-pixels" total-pixels)    ; metrics.clj:8-9
-    (save-ppm filename rgb8 nx ny)
+    (if (.endsWith (.toLowerCase ^String filename) ".ppm")
+      (save-ppm filename rgb8 nx ny)
+      (save-image filename rgb8 nx ny))
     (println "wrote" filename)))                                     ; core.clj:113

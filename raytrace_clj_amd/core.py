@@ -294,6 +294,23 @@ def save_ppm(path, rgb8):
         f.write(np.ascontiguousarray(rgb8, np.uint8).tobytes())
 
 
+def save_png(path, rgb8):
+    """imagez `save` (core.clj:112) writes whatever the extension says, PNG by default (core.clj:76): 8-bit RGB, no alpha,
+    one zlib stream, filter 0 on every row (stdlib only)."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(rgb8, np.uint8)
+    h, w, _ = a.shape
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), a.reshape(h, w * 3)], axis=1).tobytes()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
 SCENES = {  # the scene choices of core.clj:82-90 (there: commented-out lines; here: the 5th argument)
     "random": lambda s, nx, ny: s.make_random_scene(nx, ny, 11, True),      # core.clj:89, the Shirley cover scene
     "final": lambda s, nx, ny: s.make_final(nx, ny),                        # core.clj:90, the line that is active as shipped
@@ -314,7 +331,7 @@ def main(argv=None):
     window switch, is accepted and ignored -- there is no display on this path)."""
     from . import scene as scenes
     argv = list(sys.argv[1:] if argv is None else argv)
-    name = argv[0] if len(argv) > 0 else "render.ppm"
+    name = argv[0] if len(argv) > 0 else "render.png"  # core.clj:76
     nx = int(argv[1]) if len(argv) > 1 else 200
     ny = int(argv[2]) if len(argv) > 2 else 100
     nr = int(argv[3]) if len(argv) > 3 else 100
@@ -329,8 +346,10 @@ def main(argv=None):
     print("total-rays %d total-pixels %d" % (int(cnt[0]), int(cnt[1])))  # metrics.clj:8-9
     if name.lower().endswith(".ppm"):
         save_ppm(name, rgb8)
-    else:
+    elif name.lower().endswith(".npy"):
         np.save(name, rgb8)
+    else:
+        save_png(name, rgb8)
     print("wrote", name)  # core.clj:113
     return 0
 

@@ -757,6 +757,10 @@ def test_cli_renders_make_final(tmp_path):
     assert core.main([str(out), "64", "64", "4", "final"]) == 0
     img = np.frombuffer(out.read_bytes()[len(b"P6\n64 64\n255\n"):], np.uint8).reshape(64, 64, 3)
     assert img.mean() > 20 and img.std() > 10
+    png = tmp_path / "final.png"  # the reference's default output format (core.clj:76): same pixels
+    assert core.main([str(png), "64", "64", "4", "final"]) == 0
+    from test_host import _decode_png
+    assert np.array_equal(_decode_png(png.read_bytes()), img)
     with pytest.raises(SystemExit):
         core.main([str(out), "8", "8", "1", "no-such-scene"])
 

@@ -204,3 +204,36 @@ def test_product_does_not_import_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in src.replace("no oracle", ""), fn
+
+
+def _decode_png(data):
+    """minimal reader for what save_png writes (8-bit RGB, filter 0)"""
+    import struct
+    import zlib
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == (zlib.crc32(tag + body) & 0xFFFFFFFF)
+        if tag == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
+            assert (depth, ctype) == (8, 2)
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 3)
+
+
+def test_png_and_ppm_writers_round_trip(tmp_path):
+    """the reference saves a PNG through imagez (core.clj:76,112); here: stdlib writers"""
+    from raytrace_clj_amd import core
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    core.save_png(tmp_path / "a.png", img)
+    assert np.array_equal(_decode_png((tmp_path / "a.png").read_bytes()), img)
+    core.save_ppm(tmp_path / "a.ppm", img)
+    data = (tmp_path / "a.ppm").read_bytes()
+    assert data.startswith(b"P6\n53 37\n255\n") and np.array_equal(np.frombuffer(data[len(b"P6\n53 37\n255\n"):], np.uint8).reshape(37, 53, 3), img)
