@@ -713,15 +713,32 @@ __device__ inline void ext_update(ExtHit &H, double t, int idx, bool incl) {
 }
 
 struct LocalRay { double ox, oy, oz, dx, dy, dz; };
+// Scene arrays are read-only for the whole launch.  UNIFORM = the index is the same for every lane of the wave (the big
+// primitives, the flat scan, a medium's boundary list): read through the constant address space, i.e. the scalar data cache
+// into SGPRs, and every kind / chain branch is a scalar branch.  Per-lane indices (BVH leaves, the winner) use vector loads.
+template <bool UNIFORM> __device__ inline double ext_ld(const double *p, size_t i) {
+    if (UNIFORM) return reinterpret_cast<const __attribute__((address_space(4))) double *>((const __attribute__((address_space(4))) void *)(p))[i];
+    return p[i];
+}
+template <bool UNIFORM> __device__ inline int4 ext_ld_info(const int *p, int idx) {
+    if (UNIFORM) {
+        typedef int i4 __attribute__((ext_vector_type(4)));
+        const i4 v = reinterpret_cast<const __attribute__((address_space(4))) i4 *>((const __attribute__((address_space(4))) void *)(p))[idx];
+        return make_int4(v.x, v.y, v.z, v.w);
+    }
+    return reinterpret_cast<const int4 *>(p)[idx];
+}
 // the ray as the innermost record sees it: Translate subtracts its offset from the origin (hitable.clj:394), RotateY
 // pre-rotates origin and direction (hitable.clj:423-429); outermost wrapper first
+template <bool UNIFORM = false>
 __device__ inline LocalRay ext_local_ray(SceneRef sc, int first, int count, const Path<double> &P) {
     LocalRay r = {P.ox, P.oy, P.oz, P.dx, P.dy, P.dz};
     for (int k = 0; k < count; ++k) {
-        const double *q = sc.ext_xf + (size_t)(first + k) * 4;
-        if (q[0] == 0.0) { r.ox = r.ox - q[1]; r.oy = r.oy - q[2]; r.oz = r.oz - q[3]; }
+        const size_t q = (size_t)(first + k) * 4;
+        const double q0 = ext_ld<UNIFORM>(sc.ext_xf, q), q1 = ext_ld<UNIFORM>(sc.ext_xf, q + 1), q2 = ext_ld<UNIFORM>(sc.ext_xf, q + 2);
+        if (q0 == 0.0) { const double q3 = ext_ld<UNIFORM>(sc.ext_xf, q + 3); r.ox = r.ox - q1; r.oy = r.oy - q2; r.oz = r.oz - q3; }
         else {
-            const double sn = q[1], cs = q[2];
+            const double sn = q1, cs = q2;
             const double ox = cs * r.ox - sn * r.oz, oz = sn * r.ox + cs * r.oz;
             const double dx = cs * r.dx - sn * r.dz, dz = sn * r.dx + cs * r.dz;
             r.ox = ox; r.oz = oz; r.dx = dx; r.dz = dz;
@@ -733,15 +750,16 @@ __device__ inline void cross3(double ax, double ay, double az, double bx, double
     x = ay * bz - az * by; y = az * bx - ax * bz; z = ax * by - ay * bx;
 }
 // Moeller-Trumbore exactly as hitable.clj:551-563 (one sided: det > 1e-8); returns false when there is no candidate
-__device__ inline bool tri_mt(const double *g, const LocalRay &r, double &u, double &v, double &t) {
-    const double e1x = g[3] - g[0], e1y = g[4] - g[1], e1z = g[5] - g[2];
-    const double e2x = g[6] - g[0], e2y = g[7] - g[1], e2z = g[8] - g[2];
+__device__ inline bool tri_mt(double g0, double g1, double g2, double g3, double g4, double g5, double g6, double g7, double g8, const LocalRay &r,
+                              double &u, double &v, double &t) {
+    const double e1x = g3 - g0, e1y = g4 - g1, e1z = g5 - g2;
+    const double e2x = g6 - g0, e2y = g7 - g1, e2z = g8 - g2;
     double px, py, pz;
     cross3(r.dx, r.dy, r.dz, e2x, e2y, e2z, px, py, pz);
     const double det = dot3(e1x, e1y, e1z, px, py, pz);
     if (!(det > 0.00000001)) return false;
     const double inv_det = 1.0 / det;
-    const double tx = r.ox - g[0], ty = r.oy - g[1], tz = r.oz - g[2];
+    const double tx = r.ox - g0, ty = r.oy - g1, tz = r.oz - g2;
     u = dot3(tx, ty, tz, px, py, pz) * inv_det;
     if (!(u > 0.0 && u <= 1.0)) return false;
     double qx, qy, qz;
@@ -759,19 +777,23 @@ __device__ inline void rect_axes(int kind, int &ax, int &ua, int &va) {
 }
 
 // hit? of primitive idx (any kind, through its instance chain) folded into the any-order state
+template <bool UNIFORM = false>
 __device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P, double tmin, ExtHit &H) {
-    const int4 info = reinterpret_cast<const int4 *>(sc.ext_info)[idx];
-    const LocalRay r = ext_local_ray(sc, info.z, info.w, P);
-    const double *g = sc.exact12 + (size_t)idx * 12;
+    const int4 info = ext_ld_info<UNIFORM>(sc.ext_info, idx);
     const int kind = info.x;
     if (kind == RTMI_PRIM_MEDIUM) return; // media are evaluated after the surfaces, in index order (ext_medium_test)
+    const LocalRay r = ext_local_ray<UNIFORM>(sc, info.z, info.w, P);
+    const size_t gi = (size_t)idx * 12;
+    const double g0 = ext_ld<UNIFORM>(sc.exact12, gi), g1 = ext_ld<UNIFORM>(sc.exact12, gi + 1), g2 = ext_ld<UNIFORM>(sc.exact12, gi + 2),
+                 g3 = ext_ld<UNIFORM>(sc.exact12, gi + 3);
     if (kind <= RTMI_PRIM_MOVING) {
         Prim4<double> s;
-        s.cx = g[0]; s.cy = g[1]; s.cz = g[2]; s.r2 = g[3];
+        s.cx = g0; s.cy = g1; s.cz = g2; s.r2 = g3;
         if (kind == RTMI_PRIM_MOVING) {
-            const double t0 = g[7], t1 = g[8];
+            const double g4 = ext_ld<UNIFORM>(sc.exact12, gi + 4), g5 = ext_ld<UNIFORM>(sc.exact12, gi + 5), g6 = ext_ld<UNIFORM>(sc.exact12, gi + 6);
+            const double t0 = ext_ld<UNIFORM>(sc.exact12, gi + 7), t1 = ext_ld<UNIFORM>(sc.exact12, gi + 8);
             const double f = (P.time - t0) / (t1 - t0), omf = 1.0 - f;
-            s.cx = g[0] * omf + g[4] * f; s.cy = g[1] * omf + g[5] * f; s.cz = g[2] * omf + g[6] * f;
+            s.cx = g0 * omf + g4 * f; s.cy = g1 * omf + g5 * f; s.cz = g2 * omf + g6 * f;
         }
         Path<double> L; L.ox = r.ox; L.oy = r.oy; L.oz = r.oz; L.dx = r.dx; L.dy = r.dy; L.dz = r.dz;
         const double a = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
@@ -784,16 +806,29 @@ __device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P
             if (t > tmin) ext_update(H, t, idx, false);
         }
     } else if (kind <= RTMI_PRIM_RECT_YZ) {
-        int ax, ua, va;
-        rect_axes(kind, ax, ua, va);
-        const double t = (g[4] - pick3(ax, r.ox, r.oy, r.oz)) / pick3(ax, r.dx, r.dy, r.dz);
-        if (t >= tmin) {
-            const double x = pick3(ua, r.ox, r.oy, r.oz) + t * pick3(ua, r.dx, r.dy, r.dz), y = pick3(va, r.ox, r.oy, r.oz) + t * pick3(va, r.dx, r.dy, r.dz);
-            if (x >= g[0] && x <= g[2] && y >= g[1] && y <= g[3]) ext_update(H, t, idx, true);
+        const double gk = ext_ld<UNIFORM>(sc.exact12, gi + 4);
+        // the rectangle's plane axis a and its two in-plane axes u, v
+        auto rect = [&](double oa, double da, double ou, double du, double ov, double dv) {
+            const double t = (gk - oa) / da;
+            if (t >= tmin) {
+                const double x = ou + t * du, y = ov + t * dv;
+                if (x >= g0 && x <= g2 && y >= g1 && y <= g3) ext_update(H, t, idx, true);
+            }
+        };
+        if (UNIFORM) { // scalar branches on the kind, one copy of the test per kind: no selects, no indexed temporaries
+            if (kind == RTMI_PRIM_RECT_XY) rect(r.oz, r.dz, r.ox, r.dx, r.oy, r.dy);
+            else if (kind == RTMI_PRIM_RECT_XZ) rect(r.oy, r.dy, r.ox, r.dx, r.oz, r.dz);
+            else rect(r.ox, r.dx, r.oy, r.dy, r.oz, r.dz);
+        } else {
+            int ax, ua, va;
+            rect_axes(kind, ax, ua, va);
+            rect(pick3(ax, r.ox, r.oy, r.oz), pick3(ax, r.dx, r.dy, r.dz), pick3(ua, r.ox, r.oy, r.oz), pick3(ua, r.dx, r.dy, r.dz),
+                 pick3(va, r.ox, r.oy, r.oz), pick3(va, r.dx, r.dy, r.dz));
         }
     } else {
         double u, v, t;
-        if (tri_mt(g, r, u, v, t) && t >= tmin) ext_update(H, t, idx, true);
+        if (tri_mt(g0, g1, g2, g3, ext_ld<UNIFORM>(sc.exact12, gi + 4), ext_ld<UNIFORM>(sc.exact12, gi + 5), ext_ld<UNIFORM>(sc.exact12, gi + 6),
+                   ext_ld<UNIFORM>(sc.exact12, gi + 7), ext_ld<UNIFORM>(sc.exact12, gi + 8), r, u, v, t) && t >= tmin) ext_update(H, t, idx, true);
     }
 }
 
@@ -803,24 +838,25 @@ __device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P
 // un-narrowed interval, as in the reference's bvh-node descent (hitable.clj:99-105).
 __device__ inline void ext_medium_test(SceneRef sc, int idx, Path<double> &P, double tmin, double tmax, ExtHit &H) {
     const double FMAX = 3.4028234663852886e38;
-    const double *g = sc.exact12 + (size_t)idx * 12;
-    const int first = (int)g[1], count = (int)g[2];
+    const size_t gi = (size_t)idx * 12; // idx comes from media_idx: wave-uniform
+    const double density = ext_ld<true>(sc.exact12, gi);
+    const int first = (int)ext_ld<true>(sc.exact12, gi + 1), count = (int)ext_ld<true>(sc.exact12, gi + 2);
     ExtHit h1 = {FMAX, 0x7fffffff, -1, false};
-    for (int k = 0; k < count; ++k) ext_prim_test(sc, first + k, P, -FMAX, h1);
+    for (int k = 0; k < count; ++k) ext_prim_test<true>(sc, first + k, P, -FMAX, h1); // idx (a medium of media_idx) is wave-uniform
     if (!h1.any) return;
     ExtHit h2 = {FMAX, 0x7fffffff, -1, false};
-    for (int k = 0; k < count; ++k) ext_prim_test(sc, first + k, P, h1.t + 0.0001, h2);
+    for (int k = 0; k < count; ++k) ext_prim_test<true>(sc, first + k, P, h1.t + 0.0001, h2);
     if (!h2.any) return;
     double t1 = h1.t, t2 = h2.t;
     if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
     if (!(t1 < t2)) return;
     if (t1 < 0.0) t1 = 0.0;
-    const int4 info = reinterpret_cast<const int4 *>(sc.ext_info)[idx];
-    const LocalRay r = ext_local_ray(sc, info.z, info.w, P);
+    const int4 info = ext_ld_info<true>(sc.ext_info, idx);
+    const LocalRay r = ext_local_ray<true>(sc, info.z, info.w, P);
     const double mag = ::sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
     const double dist_in = (t2 - t1) * mag;
-    const double hit_distance = -(::log(next_uniform(P)) / g[0]);
+    const double hit_distance = -(::log(next_uniform(P)) / density);
     if (hit_distance < dist_in) ext_update(H, t1 + hit_distance / mag, idx, true);
 }
 
@@ -834,10 +870,10 @@ __device__ inline void scan_all_cull_ext(SceneRef sc, const Path<double> &P, dou
         const CullGroup G = load_cull_group(sc.cull20, g >> 2);
         const float d0 = cull_disc(G, 0, c), d1 = cull_disc(G, 1, c), d2 = cull_disc(G, 2, c), d3 = cull_disc(G, 3, c);
         if (fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)) >= 0.0f) {
-            if (d0 >= 0.0f) ext_prim_test(sc, g, P, tmin, H);
-            if (d1 >= 0.0f && g + 1 <= last) ext_prim_test(sc, g + 1, P, tmin, H);
-            if (d2 >= 0.0f && g + 2 <= last) ext_prim_test(sc, g + 2, P, tmin, H);
-            if (d3 >= 0.0f && g + 3 <= last) ext_prim_test(sc, g + 3, P, tmin, H);
+            if (d0 >= 0.0f) ext_prim_test<true>(sc, g, P, tmin, H);
+            if (d1 >= 0.0f && g + 1 <= last) ext_prim_test<true>(sc, g + 1, P, tmin, H);
+            if (d2 >= 0.0f && g + 2 <= last) ext_prim_test<true>(sc, g + 2, P, tmin, H);
+            if (d3 >= 0.0f && g + 3 <= last) ext_prim_test<true>(sc, g + 3, P, tmin, H);
         }
     }
 }
@@ -847,13 +883,13 @@ __device__ inline float ext_best_hi(const ExtHit &H) { return H.t < 3.0e38 ? flo
 __device__ inline void scan_bvh_ext(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, ExtHit &H) {
     const BvhRay r = make_bvh_ray(sc, P, a, tmin);
     if (!r.ok) { scan_all_cull_ext(sc, P, a, tmin, H); return; }
-    for (int k = 0; k < sc.n_big; ++k) ext_prim_test(sc, sc.big_idx[k], P, tmin, H);
-    auto leaf = [&](int code) { ext_prim_test(sc, (~code) & 0x3fffffff, P, tmin, H); };
+    for (int k = 0; k < sc.n_big; ++k) ext_prim_test<true>(sc, sc.big_idx[k], P, tmin, H);
+    auto leaf = [&](int code) { ext_prim_test<false>(sc, (~code) & 0x3fffffff, P, tmin, H); };
     auto best = [&]() { return ext_best_hi(H); };
     if (__any(r.far ? 1 : 0)) bvh_traverse<true>(sc, stack, r, leaf, best);
     else bvh_traverse<false>(sc, stack, r, leaf, best);
     if (!r.time_ok) // e.g. after Isotropic.scatter, which sets the ray's time to the hit's t (shader.clj:136)
-        for (int k = 0; k < sc.n_moving_all; ++k) ext_prim_test(sc, sc.moving_all[k], P, tmin, H);
+        for (int k = 0; k < sc.n_moving_all; ++k) ext_prim_test<true>(sc, sc.moving_all[k], P, tmin, H);
 }
 
 // hitable.clj:219-252 (MovingSphere.hit?): centre = lerp(c0, c1, (time-t0)/(t1-t0)) per ray.
@@ -959,7 +995,7 @@ __device__ inline void resolve_hit_ext(SceneRef sc, const Path<double> &P, doubl
         nx = ax == 0 ? 1.0 : 0.0; ny = ax == 1 ? 1.0 : 0.0; nz = ax == 2 ? 1.0 : 0.0;
     } else {
         double u = 0.0, v = 0.0, tt;
-        tri_mt(g, r, u, v, tt);
+        tri_mt(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], r, u, v, tt);
         h.u = u; h.v = v;
         cross3(g[3] - g[0], g[4] - g[1], g[5] - g[2], g[6] - g[0], g[7] - g[1], g[8] - g[2], nx, ny, nz); // not normalised (hitable.clj:570)
     }
