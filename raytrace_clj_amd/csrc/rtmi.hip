@@ -689,7 +689,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
 
 // ---- RTMI_ACCEL_BVH host build ----------------------------------------------------------------------------------------
 // Binned-SAH binary BVH over the primitives' boxes, one primitive per leaf, each node carrying its two children's boxes
-// (one 64-byte fetch per step).  Boxes are FLOAT, rounded outward and inflated by 2^-22 * obound (see box_hit): the
+// (one 64-byte fetch per step).  Boxes are FLOAT, rounded outward and inflated by 2^-22 * obound (see slab_hit): the
 // traversal is only a conservative filter in front of the exact FP64 sphere test, so the tree's shape affects speed, never
 // results.  Primitives whose radius is a large fraction of the scene (sky dome, ground) are kept out of the tree.
 struct BvhBox { double lo[3], hi[3]; };
@@ -709,11 +709,18 @@ struct BvhBuilder {
     int leaf_code(int idx) const { return ~(idx | (moving[(size_t)idx] ? 0x40000000 : 0)); }
     int sah_depth = 8, max_depth = 0;
     BvhBox bounds(int b, int e) const { BvhBox r = box_empty(); for (int i = b; i < e; ++i) box_grow(r, items[(size_t)i].b); return r; }
+    // node record (16 floats): l.lo.xy l.hi.xy | r.lo.xy r.hi.xy | l.lo.z l.hi.z r.lo.z r.hi.z | left, right, 0, 0
     void put_box(int node, int side, const BvhBox &b) {
-        float *q = &nodes[(size_t)node * 16 + (size_t)side * 6];
-        for (int k = 0; k < 3; ++k) { q[k] = f_down(b.lo[k] - delta); q[3 + k] = f_up(b.hi[k] + delta); }
+        float *q = &nodes[(size_t)node * 16];
+        for (int k = 0; k < 2; ++k) { q[side * 4 + k] = f_down(b.lo[k] - delta); q[side * 4 + 2 + k] = f_up(b.hi[k] + delta); }
+        q[8 + side * 2] = f_down(b.lo[2] - delta); q[8 + side * 2 + 1] = f_up(b.hi[2] + delta);
     }
-    int build(int b, int e, int depth) { // returns the child code of the subtree over items [b, e)
+    void put_empty_box(int node, int side) {
+        float *q = &nodes[(size_t)node * 16];
+        for (int k = 0; k < 2; ++k) { q[side * 4 + k] = INFINITY; q[side * 4 + 2 + k] = -INFINITY; }
+        q[8 + side * 2] = INFINITY; q[8 + side * 2 + 1] = -INFINITY;
+    }
+    int build(int b, int e, int depth) { // returns the child code of the subtree over items [b, e): byte offset of the node, or a leaf code
         max_depth = std::max(max_depth, depth);
         if (e - b == 1) return leaf_code(items[(size_t)b].idx);
         const int node = (int)(nodes.size() / 16);
@@ -761,7 +768,7 @@ struct BvhBuilder {
         put_box(node, 1, rb);
         std::memcpy(&nodes[(size_t)node * 16 + 12], &l, 4);
         std::memcpy(&nodes[(size_t)node * 16 + 13], &r, 4);
-        return node;
+        return node * 64;
     }
 };
 
@@ -842,7 +849,7 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
     else if (B.items.size() == 1) { // a lone primitive: a node whose right child is an empty box
         B.nodes.assign(16, 0.0f);
         B.put_box(0, 0, B.items[0].b);
-        for (int k = 0; k < 3; ++k) { B.nodes[6 + (size_t)k] = INFINITY; B.nodes[9 + (size_t)k] = -INFINITY; }
+        B.put_empty_box(0, 1);
         const int l = B.leaf_code(B.items[0].idx), r = l;
         std::memcpy(&B.nodes[12], &l, 4); std::memcpy(&B.nodes[13], &r, 4);
         d.bvh_root = 0;
@@ -851,7 +858,7 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
         while ((1u << lg) < B.items.size()) ++lg;
         B.sah_depth = std::max(2, RTMI_BVH_STACK - 2 - lg); // SAH levels + median levels (<= lg) stay below the stack size
         d.bvh_root = B.build(0, (int)B.items.size(), 0);
-        if (B.max_depth >= RTMI_BVH_STACK - 1) { // cannot happen by construction; never risk the traversal stack
+        if (B.max_depth >= RTMI_BVH_STACK - 1 || B.nodes.size() / 16 >= (1u << 25)) { // cannot happen by construction / node byte offsets are 31-bit
             d.bvh_root = RTMI_BVH_EMPTY; d.n_big = 0; d.bvh_obound = -1.0f; // obound < 0: every ray takes the exact flat scan
             B.nodes.clear();
         }

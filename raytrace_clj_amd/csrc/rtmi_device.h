@@ -30,7 +30,7 @@ struct DevScene {
     const double *exact12;   // [round_up(n_all,8)+8][12] c0.xyz r*r c1.xyz t0 t1 moving? 0 0 (padded with copies of the last)
     double cull_t_lo, cull_t_hi; // ray times the swept bounds are valid for (the camera's [t0, t1])
     // RTMI_ACCEL_BVH (the reference's bvh-node descent, hitable.clj:97-123, rebuilt for the device):
-    const float *bvh_nodes;  // [n_nodes][16]: left box lo.xyz hi.xyz, right box lo.xyz hi.xyz, left, right (int bits), 0, 0
+    const float *bvh_nodes;  // [n_nodes][16]: l.lo.xy l.hi.xy r.lo.xy r.hi.xy l.lo.z l.hi.z r.lo.z r.hi.z, left, right (int bits), 0, 0
     int bvh_root;            // child code: >= 0 node index, < 0 = ~(original primitive index | moving << 30), 0x7fffffff = empty
     int n_big;               // primitives too large to bound usefully (sky dome, ground): always tested exactly
     int big_idx[16];
@@ -556,22 +556,17 @@ __device__ inline void exact_prim_test_lane(const double *exact12, int code, con
 // Conservative slab test in float, FMA form: t = plane * inv_d + (-o * inv_d).  Error budget: the rounding of
 // c = fl(-o_f * inv) and of the fma are each equivalent to moving the plane by <= 2^-24 |o| (plus a relative 2u on t), and
 // |fl32(o) - o| <= 2^-24 |o|; the box planes were rounded outward and inflated by 2^-22 * obound >= 4 * 2^-24 |o| on the
-// host, which covers all three for every ray with |o| <= obound.  A ray that starts OUTSIDE the scene bound (FAR: e.g.
-// after scattering in a scene-sized ConstantMedium) widens every slab by its own e = 2^-22 |o|_inf instead (ex = e |inv_x|,
-// ...).  The remaining relative error (<= 4u with the rounding of inv) is absorbed by lowering the entry distance and
-// raising the exit distance by 8u before comparing.
-template <bool FAR>
-__device__ inline bool box_hit(const float lo0, const float lo1, const float lo2, const float hi0, const float hi1, const float hi2,
-                               const float cx, const float cy, const float cz, const float ix, const float iy, const float iz,
-                               const float ex, const float ey, const float ez, const float tmin_lo, const float best_hi, float &tnear) {
-    const float ax = fmaf(lo0, ix, cx), bx = fmaf(hi0, ix, cx);
-    const float ay = fmaf(lo1, iy, cy), by = fmaf(hi1, iy, cy);
-    const float az = fmaf(lo2, iz, cz), bz = fmaf(hi2, iz, cz);
-    float nx = fminf(ax, bx), ny = fminf(ay, by), nz = fminf(az, bz);
-    float fx = fmaxf(ax, bx), fy = fmaxf(ay, by), fz = fmaxf(az, bz);
-    if (FAR) { nx -= ex; ny -= ey; nz -= ez; fx += ex; fy += ey; fz += ez; }
-    float tn = fmaxf(fmaxf(nx, ny), nz);
-    float tf = fminf(fminf(fx, fy), fz);
+// host, which covers all three for every ray with |o| <= obound.  A ray that starts OUTSIDE the scene bound (far: e.g.
+// after scattering in a scene-sized ConstantMedium) moves every plane outward by its own e = 2^-21 |o|_inf instead: the slack
+// e |inv| is folded into the additive constant per plane (c_lo for the planes x = lo, c_hi for x = hi; which of the two is
+// the entry plane is the sign of inv), one more rounding of the same size, hence 2^-21.  The remaining relative error (<= 4u
+// with the rounding of inv) is absorbed by lowering the entry distance and raising the exit distance by 8u before comparing.
+// Both children of a node are tested together; the x/y planes go through packed FMAs (v_pk_fma_f32), z as (lo, hi) pairs.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct BvhRay { v2f ixy, izz, clxy, chxy, czz; float tmin_lo; bool ok, far, time_ok; };
+__device__ inline bool slab_hit(const v2f a, const v2f b, const v2f z, const float tmin_lo, const float best_hi, float &tnear) {
+    float tn = fmaxf(fmaxf(fminf(a.x, b.x), fminf(a.y, b.y)), fminf(z.x, z.y));
+    float tf = fminf(fminf(fmaxf(a.x, b.x), fmaxf(a.y, b.y)), fmaxf(z.x, z.y));
     const float ku = 8.0f * 5.9604645e-08f;
     tn = fmaf(-ku, fabsf(tn), tn);
     tf = fmaf(ku, fabsf(tf), tf);
@@ -586,22 +581,25 @@ __device__ inline float float_up(double x) { // smallest float >= x (x finite, |
 }
 
 // what the float traversal needs to know about a ray; ok = false: take the exact flat scan instead
-struct BvhRay { float ox, oy, oz, ix, iy, iz, cx, cy, cz, ex, ey, ez, tmin_lo; bool ok, far, time_ok; };
 __device__ inline BvhRay make_bvh_ray(SceneRef sc, const Path<double> &P, double a, double tmin) {
     BvhRay r;
-    r.ox = (float)P.ox; r.oy = (float)P.oy; r.oz = (float)P.oz;
+    const float ox = (float)P.ox, oy = (float)P.oy, oz = (float)P.oz;
     const float dx = (float)P.dx, dy = (float)P.dy, dz = (float)P.dz;
     const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-    const float omax = fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fabsf(r.oz));
+    const float omax = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
     // not boundable in float: non-finite values, a vanishing direction component (1/d would overflow), absurd magnitudes
     r.ok = (omax < 1e15f) && (dmax < 1e15f) && (dmax > 1e-15f) && (fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= 1e-12f * dmax) &&
            (a > 1e-30) && (a < 1e30) && (tmin > -1e30) && (tmin < 1e30) && (sc.bvh_obound >= 0.0f);
     r.far = omax > sc.bvh_obound;
     r.time_ok = (P.time >= sc.cull_t_lo) && (P.time <= sc.cull_t_hi); // else the MovingSphere boxes do not bound this ray's spheres
-    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
-    r.cx = -r.ox * r.ix; r.cy = -r.oy * r.iy; r.cz = -r.oz * r.iz;
-    const float e = r.far ? omax * (1.0001f / 4194304.0f) : 0.0f;
-    r.ex = e * fabsf(r.ix); r.ey = e * fabsf(r.iy); r.ez = e * fabsf(r.iz);
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float cx = -ox * ix, cy = -oy * iy, cz = -oz * iz;
+    const float e = r.far ? omax * (1.0001f / 2097152.0f) : 0.0f;
+    // signed slack: the plane x = lo is the entry plane when inv >= 0 (entry distances are lowered, exit distances raised)
+    const float ex = e * ix, ey = e * iy, ez = e * iz; // = e |inv| * sign(inv)
+    r.ixy = v2f{ix, iy}; r.izz = v2f{iz, iz};
+    r.clxy = v2f{cx - ex, cy - ey}; r.chxy = v2f{cx + ex, cy + ey};
+    r.czz = v2f{cz - ez, cz + ez};
     r.tmin_lo = r.ok ? -float_up(-tmin) : 0.0f;
     return r;
 }
@@ -618,63 +616,43 @@ __device__ inline unsigned long long stamp_now() {
     return t;
 }
 #endif
-template <bool FAR, typename Leaf, typename BestHi>
+template <typename Leaf, typename BestHi>
 __device__ inline void bvh_traverse(SceneRef sc, int *stack, const BvhRay &r, Leaf leaf, BestHi best) {
-    int node = sc.bvh_root;
+    int node = sc.bvh_root; // inner node: byte offset of its record (>= 0); leaf: ~(primitive | moving << 30) (< 0)
     if (node == RTMI_BVH_EMPTY) return;
-    const int tid = threadIdx.x, stride = blockDim.x;
-    int sp = 0;
-    const float4 *nodes = reinterpret_cast<const float4 *>(sc.bvh_nodes);
+    const int stride = blockDim.x;
+    int *const base = stack + threadIdx.x;
+    int *top = base; // next free slot of this thread's column
+    const char *nodes = reinterpret_cast<const char *>(sc.bvh_nodes);
     float best_hi = best();
-#ifdef RTMI_STAMPS_BVH
-    __shared__ unsigned st_w[4][4]; // per wave: inner trips, inner lane-trips, leaf trips, leaf lane-trips (written by one lane at a time)
-    const int st_wave = threadIdx.x >> 6, st_lane = threadIdx.x & 63;
-    if (st_lane == __ffsll((long long)__ballot(1)) - 1) { st_w[st_wave][0] = 0; st_w[st_wave][1] = 0; st_w[st_wave][2] = 0; st_w[st_wave][3] = 0; }
-    __shared__ unsigned long long st_c[4][2]; // per wave: ticks in the inner loop, ticks in the leaf tests
-    if (st_lane == __ffsll((long long)__ballot(1)) - 1) { st_c[st_wave][0] = 0; st_c[st_wave][1] = 0; }
-    unsigned long long s_t = stamp_now();
-#endif
     while (node != RTMI_BVH_EMPTY) {
         while (node >= 0 && node != RTMI_BVH_EMPTY) { // inner node: both child boxes come with it (one 64-byte record)
-#ifdef RTMI_STAMPS_BVH
-            { const unsigned long long m_ = __ballot(1); if (st_lane == __ffsll((long long)m_) - 1) { st_w[st_wave][0] += 1; st_w[st_wave][1] += __popcll(m_); } }
-#endif
-            const float4 n0 = nodes[(size_t)node * 4], n1 = nodes[(size_t)node * 4 + 1], n2 = nodes[(size_t)node * 4 + 2], n3 = nodes[(size_t)node * 4 + 3];
+            // record: l.lo.xy l.hi.xy | r.lo.xy r.hi.xy | l.lo.z l.hi.z r.lo.z r.hi.z | left, right
+            const float4 *q = reinterpret_cast<const float4 *>(nodes + (unsigned)node);
+            const float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
             float tl, tr;
-            const bool hl = box_hit<FAR>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r.cx, r.cy, r.cz, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tmin_lo, best_hi, tl);
-            const bool hr = box_hit<FAR>(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r.cx, r.cy, r.cz, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tmin_lo, best_hi, tr);
+            const bool hl = slab_hit(__builtin_elementwise_fma(v2f{n0.x, n0.y}, r.ixy, r.clxy), __builtin_elementwise_fma(v2f{n0.z, n0.w}, r.ixy, r.chxy),
+                                     __builtin_elementwise_fma(v2f{n2.x, n2.y}, r.izz, r.czz), r.tmin_lo, best_hi, tl);
+            const bool hr = slab_hit(__builtin_elementwise_fma(v2f{n1.x, n1.y}, r.ixy, r.clxy), __builtin_elementwise_fma(v2f{n1.z, n1.w}, r.ixy, r.chxy),
+                                     __builtin_elementwise_fma(v2f{n2.z, n2.w}, r.izz, r.czz), r.tmin_lo, best_hi, tr);
             const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
             if (hl && hr) {
                 const bool left_first = tl <= tr;
-                stack[sp * stride + tid] = left_first ? cr : cl;
-                ++sp;
+                *top = left_first ? cr : cl;
+                top += stride;
                 node = left_first ? cl : cr;
             } else if (hl) node = cl;
             else if (hr) node = cr;
-            else if (sp > 0) { --sp; node = stack[sp * stride + tid]; }
+            else if (top != base) { top -= stride; node = *top; }
             else node = RTMI_BVH_EMPTY;
         }
-#ifdef RTMI_STAMPS_BVH
-        { const unsigned long long n_ = stamp_now(); if (st_lane == __ffsll((long long)__ballot(1)) - 1) st_c[st_wave][0] += n_ - s_t; s_t = n_; }
-        if (node != RTMI_BVH_EMPTY) { const unsigned long long m_ = __ballot(1); if (st_lane == __ffsll((long long)m_) - 1) { st_w[st_wave][2] += 1; st_w[st_wave][3] += __popcll(m_); } }
-#endif
         if (node != RTMI_BVH_EMPTY) { // leaf: one primitive, exact FP64 test
             leaf(node);
             best_hi = best();
-            if (sp > 0) { --sp; node = stack[sp * stride + tid]; }
+            if (top != base) { top -= stride; node = *top; }
             else node = RTMI_BVH_EMPTY;
         }
-#ifdef RTMI_STAMPS_BVH
-        { const unsigned long long n_ = stamp_now(); if (st_lane == __ffsll((long long)__ballot(1)) - 1) st_c[st_wave][1] += n_ - s_t; s_t = n_; }
-#endif
     }
-#ifdef RTMI_STAMPS_BVH
-    if (st_lane == __ffsll((long long)__ballot(1)) - 1) { // s_in / s_lf are wave times (s_memtime is scalar): one lane reports
-        atomicAdd(&g_stamps2[0], st_c[st_wave][0]); atomicAdd(&g_stamps2[1], st_c[st_wave][1]); atomicAdd(&g_stamps2[2], (unsigned long long)st_w[st_wave][0]);
-        atomicAdd(&g_stamps2[3], (unsigned long long)st_w[st_wave][1]); atomicAdd(&g_stamps2[4], (unsigned long long)st_w[st_wave][2]);
-        atomicAdd(&g_stamps2[5], (unsigned long long)st_w[st_wave][3]); atomicAdd(&g_stamps2[6], 1ull);
-    }
-#endif
 }
 
 __device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, double &best_t, int &best_i) {
@@ -690,8 +668,7 @@ __device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<double> &P, 
     // 2. the tree
     auto leaf = [&](int code) { exact_prim_test_lane(exact12, code, P, a, tmin, behind_ok, best_t, best_i); };
     auto best = [&]() { return best_t < 3.0e38 ? float_up(best_t) : 3.4028235e38f; };
-    if (__any(r.far ? 1 : 0)) bvh_traverse<true>(sc, stack, r, leaf, best);
-    else bvh_traverse<false>(sc, stack, r, leaf, best);
+    bvh_traverse(sc, stack, r, leaf, best);
     // 3. a ray outside the shutter interval: the MovingSphere boxes were built for [t_lo, t_hi], so test every moving sphere exactly
     if (!r.time_ok)
         for (int k = 0; k < sc.n_moving_all; ++k) exact_prim_test_lane(exact12, ~(sc.moving_all[k] | 0x40000000), P, a, tmin, behind_ok, best_t, best_i);
@@ -886,8 +863,7 @@ __device__ inline void scan_bvh_ext(SceneRef sc, int *stack, const Path<double> 
     for (int k = 0; k < sc.n_big; ++k) ext_prim_test<true>(sc, sc.big_idx[k], P, tmin, H);
     auto leaf = [&](int code) { ext_prim_test<false>(sc, (~code) & 0x3fffffff, P, tmin, H); };
     auto best = [&]() { return ext_best_hi(H); };
-    if (__any(r.far ? 1 : 0)) bvh_traverse<true>(sc, stack, r, leaf, best);
-    else bvh_traverse<false>(sc, stack, r, leaf, best);
+    bvh_traverse(sc, stack, r, leaf, best);
     if (!r.time_ok) // e.g. after Isotropic.scatter, which sets the ray's time to the hit's t (shader.clj:136)
         for (int k = 0; k < sc.n_moving_all; ++k) ext_prim_test<true>(sc, sc.moving_all[k], P, tmin, H);
 }
