@@ -497,6 +497,7 @@ struct rtmi_ctx {
     int max_lds_bytes = 64 * 1024 - 64; // static-sphere LDS tile budget per workgroup
     // workspace
     DevBuf samples, accum, tiles, tile_ids, counters, scratch_lin;
+    int last_grid = 0; // workgroups of the last trace launch (diagnostics)
     std::vector<int> tile_ids_host;
     int tile_key[4] = {-1, -1, -1, -1};
     long long tile_valid_pixels = 0;
@@ -647,6 +648,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         int resident = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, kBlock, dyn_lds));
         const int grid_trace = std::max(1, c->cus * std::max(1, std::min(c->blocks_per_cu, resident)));
+        c->last_grid = grid_trace;
         hipLaunchKernelGGL(kern, dim3(grid_trace), dim3(kBlock), dyn_lds, st, s->d_dev, tp);
         HIP_TRY(hipGetLastError());
         if (e1) HIP_TRY(hipEventRecord(e1, st));
@@ -659,7 +661,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
     }
 #ifdef RTMI_STAMPS
     {
-        const int grid_trace_dbg = std::max(1, c->cus * c->blocks_per_cu);
+        const int grid_trace_dbg = c->last_grid;
         HIP_TRY(hipStreamSynchronize(st));
         unsigned long long h[8] = {0}, z[8] = {0};
         HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)));

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 
 from . import _ffi
-from .core import check
+from .core import Context, DeviceScene, check
 
 TILE = _ffi.TILE
 HOST_STAGED_GATHER = False  # rehearsal only (gloo on a one-GPU box): stage the gather through host memory
@@ -68,3 +68,52 @@ class TileRenderer:
         if self.rank == 0:
             check(_ffi.lib().rtmi_assemble_device(self.ds.ctx.handle, self.nx, self.ny, self.world, self.per, _ffi.ptr(gathered),
                                                   _ffi.ptr(self.linear), _ffi.ptr(self.rgb8), _ffi.ptr(stream)))
+
+
+class FramePipeline:
+    """`depth` frames in flight on one GPU: every slot owns a context (its own sample workspace and work queue), the scene
+    and a stream, and consecutive frames go to consecutive slots.  A path tracer's launch ends with a die-off -- the last
+    deep paths (up to `depth 50` bounces) finish in nearly empty waves; with two slots the next frame's workgroups take
+    the CU slots the previous frame's workgroups vacate, and its gather / assemble overlap the next render as well.
+    Frames are independent, so the images are those of the one-slot renderer (asserted in the GPU tests)."""
+
+    def __init__(self, flat_scene, nx, ny, rank, world, device, depth=2, timing=False, options=None):
+        self.slots = []
+        for _ in range(max(1, depth)):
+            ctx = Context(device, timing=timing)
+            for k, v in (options or {}).items():
+                ctx.set_option(k, v)
+            ds = DeviceScene(flat_scene, ctx=ctx)
+            self.slots.append((ctx, ds, TileRenderer(ds, nx, ny, rank, world), torch.cuda.Stream(device=device)))
+        self.next = 0
+        torch.cuda.synchronize(device)  # the slots' buffers were filled on the current stream
+
+    def set_option(self, name, value):
+        for ctx, _, _, _ in self.slots:
+            ctx.set_option(name, value)
+
+    def step(self, ns, **kw):
+        """enqueue one frame on the next slot; returns that slot's TileRenderer (its buffers are valid after sync())"""
+        ctx, ds, tr, stream = self.slots[self.next]
+        self.next = (self.next + 1) % len(self.slots)
+        with torch.cuda.stream(stream):
+            tr.step(ns, **kw)
+        return tr
+
+    def sync(self):
+        for _, _, _, stream in self.slots:
+            stream.synchronize()
+
+    def last_trace_ms(self):
+        """(sum of trace-kernel durations in ms, number of launches) over all slots since the last call"""
+        ms, n = 0.0, 0
+        for ctx, _, _, _ in self.slots:
+            a, b = ctx.last_trace_ms()
+            ms, n = ms + a, n + b
+        return ms, n
+
+    def close(self):
+        for ctx, ds, _, _ in self.slots:
+            ds.close()
+            ctx.close()
+        self.slots = []

@@ -380,6 +380,26 @@ def test_bench_json_schema():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"], k
     assert d["other_accel"]["accel"] == "flat" and d["other_accel"]["value"] > 100
+    assert d["config"]["frames_in_flight"] == 2 and d["serial"]["value"] > 100 and d["roofline"]["pipelined_launch_ms"] >= d["roofline"]["launch_ms"] > 0
+
+
+def test_frame_pipeline_renders_the_same_frames():
+    """two render slots on two streams (dist.FramePipeline): every frame equals the one-slot render, counters included"""
+    import torch
+    from raytrace_clj_amd import dist as rdist
+    nx, ny, ns = 200, 100, 8
+    flat = fl.flatten(r.scene.make_random_scene(nx, ny, 11, True))
+    one = rdist.FramePipeline(flat, nx, ny, 0, 1, 0, depth=1, options={"accel": 1})
+    two = rdist.FramePipeline(flat, nx, ny, 0, 1, 0, depth=2, options={"accel": 1})
+    ref = one.step(ns)
+    one.sync()
+    frames = [two.step(ns) for _ in range(5)]
+    two.sync()
+    assert frames[0] is frames[2] is frames[4] and frames[1] is frames[3] and frames[0] is not frames[1]
+    for tr in frames[:2]:
+        assert torch.equal(tr.rgb8, ref.rgb8) and torch.equal(tr.linear, ref.linear) and torch.equal(tr.counters, ref.counters)
+    assert int(ref.counters[1]) == nx * ny
+    one.close(); two.close()
 
 
 def test_bvh_full_size_image_identical():
