@@ -101,13 +101,6 @@ __device__ inline void scan_cull_dispatch(SceneRef sc, const Path<float> &P, flo
     }
 }
 
-// the BVH, like the cull, exists for the FP64 path; RTMI_F32 uses the plain scan
-__device__ inline void scan_bvh_dispatch(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, double &best_t, int &best_i) {
-    scan_bvh(sc, stack, P, a, tmin, best_t, best_i);
-}
-__device__ inline void scan_bvh_dispatch(SceneRef sc, int *, const Path<float> &P, float a, float tmin, float &best_t, int &best_i) {
-    scan_cull_dispatch(sc, P, a, tmin, best_t, best_i);
-}
 
 // hit? of the whole world for the lane's ray (closest hit, t in (t-min, t-max); core.clj:25 passes 0.001, Float/MAX_VALUE).
 // MULTI (LDS variants only): the static spheres do not fit one LDS tile; every thread of the workgroup must call this.
@@ -134,7 +127,7 @@ __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per
     best_i = -1;
     const R a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
     if (VARIANT == SCAN_BVH) { // RTMI_ACCEL_BVH; `lds` is the traversal stack
-        if (active) scan_bvh_dispatch(sc, reinterpret_cast<int *>(lds), P, a, tmin, best_t, best_i);
+        if (active) scan_bvh<R>(sc, reinterpret_cast<int *>(lds), P, a, tmin, best_t, best_i, [&]() { scan_cull_dispatch(sc, P, a, tmin, best_t, best_i); });
         return;
     }
     if (VARIANT == SCAN_SGPR_CULL) { // all primitives, original order; returns the original index
@@ -847,6 +840,9 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
     B.moving.assign((size_t)std::max(n_prims, 1), 0);
     for (int i = 0; i < n_prims; ++i) B.moving[(size_t)i] = prim_kind[i] == RTMI_PRIM_MOVING;
     d.bvh_obound = f_down(obound);
+    double cbound = 0.0;
+    for (const BvhItem &it : B.items) for (int k = 0; k < 3; ++k) cbound = std::max(cbound, std::max(std::fabs(it.b.lo[k]), std::fabs(it.b.hi[k])));
+    d.bvh_cbound = f_up(cbound);
     if (B.items.empty()) d.bvh_root = RTMI_BVH_EMPTY;
     else if (B.items.size() == 1) { // a lone primitive: a node whose right child is an empty box
         B.nodes.assign(16, 0.0f);
@@ -1068,7 +1064,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
         while (stat4_f.size() < n4 * 4) stat4_f.insert(stat4_f.end(), lf, lf + 4);
     }
     // ---- scan variant SCAN_SGPR_CULL: all primitives in Hitlist order ----
-    // exact12[i] = c0.xyz, r*r, c1.xyz, t0, t1, moving?, 0, 0 ; cull20 = FP32 bounding data per group of 4.
+    // exact12[i] = c0.xyz, r*r, c1.xyz, t0, t1, moving?, r, 0 ; cull20 = FP32 bounding data per group of 4.
     // A MovingSphere's cull entry bounds its sweep over the camera's shutter interval [t_lo, t_hi] (rays outside that
     // interval bypass the cull, make_cull_ray): centre = midpoint of the two extreme centres, radius = r + half the
     // distance between them, both inflated for the float rounding of the centre.
@@ -1103,7 +1099,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
         const volatile double r2d = g[3] * g[3];
         if (kind > RTMI_PRIM_MOVING || xf_count > 0) { // f3 primitive or instanced sphere: cull by the sphere around its world box
             if (kind > RTMI_PRIM_MOVING) exact12.insert(exact12.end(), {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], 0.0, 0.0, 0.0});
-            else exact12.insert(exact12.end(), {g[0], g[1], g[2], (double)r2d, g[4], g[5], g[6], g[7], g[8], moving ? 1.0 : 0.0, 0.0, 0.0});
+            else exact12.insert(exact12.end(), {g[0], g[1], g[2], (double)r2d, g[4], g[5], g[6], g[7], g[8], moving ? 1.0 : 0.0, g[3], 0.0});
             float cf[3] = {0, 0, 0};
             double r2b = 3.0e38, w = 3.0e38;
             if (bounded[(size_t)i]) {
@@ -1126,7 +1122,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
             cull_w.push_back((float)std::min(w, 3.0e38));
             continue;
         }
-        const double rec[12] = {g[0], g[1], g[2], (double)r2d, g[4], g[5], g[6], g[7], g[8], moving ? 1.0 : 0.0, 0.0, 0.0};
+        const double rec[12] = {g[0], g[1], g[2], (double)r2d, g[4], g[5], g[6], g[7], g[8], moving ? 1.0 : 0.0, g[3], 0.0};
         exact12.insert(exact12.end(), rec, rec + 12);
         double cm[3] = {g[0], g[1], g[2]}, rb = std::fabs(g[3]);
         bool unbounded = false;

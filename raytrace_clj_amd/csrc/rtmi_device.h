@@ -31,10 +31,11 @@ struct DevScene {
     double cull_t_lo, cull_t_hi; // ray times the swept bounds are valid for (the camera's [t0, t1])
     // RTMI_ACCEL_BVH (the reference's bvh-node descent, hitable.clj:97-123, rebuilt for the device):
     const float *bvh_nodes;  // [n_nodes][16]: l.lo.xy l.hi.xy r.lo.xy r.hi.xy l.lo.z l.hi.z r.lo.z r.hi.z, left, right (int bits), 0, 0
-    int bvh_root;            // child code: >= 0 node index, < 0 = ~(original primitive index | moving << 30), 0x7fffffff = empty
+    int bvh_root;            // child code: >= 0 byte offset of the node record, < 0 = ~(original primitive index | moving << 30), 0x7fffffff = empty
     int n_big;               // primitives too large to bound usefully (sky dome, ground): always tested exactly
     int big_idx[16];
-    float bvh_obound;        // rays starting outside [-obound, obound]^3 widen every box by 2^-22 |o| themselves
+    float bvh_obound;        // rays starting outside [-obound, obound]^3 move every box plane out by 2^-21 |o| themselves
+    float bvh_cbound;        // largest |coordinate| of the boxes in the tree (the big primitives are outside it)
     int n_moving_all;        // all MovingSphere world primitives (tested exhaustively for rays outside the shutter interval)
     const int *moving_all;
     // section 8(f3): rectangles / triangles and FlipNormals / Translate / RotateY instances (hitable.clj:269-511, 548-581)
@@ -467,35 +468,37 @@ __device__ inline float cull_disc(const CullGroup &G, int k, const CullRay &c) {
     return fmaf(b, b, t2);
 }
 
-// exact FP64 test of primitive i (original index) for the lanes that survived the cull: Sphere / UVSphere
-// (hitable.clj:180-207 / 141-168) or MovingSphere (hitable.clj:219-252, centre = lerp(c0, c1, (time-t0)/(t1-t0)))
-__device__ inline void exact_prim_test(const double *exact12, int i, int idx, const Path<double> &P, double a, double tmin, bool behind_ok,
-                                       double &best_t, int &best_i) {
+// exact test of primitive i (original index; wave-uniform: scalar loads) for the lanes that survived the cull: Sphere /
+// UVSphere (hitable.clj:180-207 / 141-168) or MovingSphere (hitable.clj:219-252, centre = lerp(c0, c1, (time-t0)/(t1-t0)))
+template <typename R>
+__device__ inline void exact_prim_test(const double *exact12, int i, int idx, const Path<R> &P, R a, R tmin, bool behind_ok, R &best_t, int &best_i) {
     typedef double d4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) d4 *cptr;
     const cptr p = (cptr)(exact12) + (size_t)i * 3;
     const d4 q0 = p[0], q2 = p[2];
-    Prim4<double> s;
-    s.cx = q0.x; s.cy = q0.y; s.cz = q0.z; s.r2 = q0.w;
+    Prim4<R> s;
+    s.cx = (R)q0.x; s.cy = (R)q0.y; s.cz = (R)q0.z;
+    if (sizeof(R) == sizeof(double)) s.r2 = (R)q0.w;
+    else { const R rad = (R)q2.z; s.r2 = rad * rad; }
     if (q2.y != 0.0) { // moving (wave-uniform branch)
         const d4 q1 = p[1];
-        const double t0 = q1.w, t1 = q2.x;
-        const double f = (P.time - t0) / (t1 - t0), omf = 1.0 - f;
-        s.cx = q0.x * omf + q1.x * f; s.cy = q0.y * omf + q1.y * f; s.cz = q0.z * omf + q1.z * f;
+        const R t0 = (R)q1.w, t1 = (R)q2.x;
+        const R f = (P.time - t0) / (t1 - t0), omf = R(1.0) - f;
+        s.cx = (R)q0.x * omf + (R)q1.x * f; s.cy = (R)q0.y * omf + (R)q1.y * f; s.cz = (R)q0.z * omf + (R)q1.z * f;
     }
-    double bq, cq, disc;
+    R bq, cq, disc;
     sphere_test(s, P, a, bq, cq, disc);
-    if (disc >= 0.0) sphere_roots(bq, cq, disc, a, tmin, behind_ok, best_t, best_i, idx);
+    if (disc >= R(0)) sphere_roots(bq, cq, disc, a, tmin, behind_ok, best_t, best_i, idx);
 }
 
 __device__ inline void cull_test_group(const CullGroup &G, int g, int last, const double *exact12, const Path<double> &P, const CullRay &c,
                                        double a, double tmin, bool behind_ok, double &best_t, int &best_i) {
     const float d0 = cull_disc(G, 0, c), d1 = cull_disc(G, 1, c), d2 = cull_disc(G, 2, c), d3 = cull_disc(G, 3, c);
     if (fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)) >= 0.0f) {
-        if (d0 >= 0.0f) exact_prim_test(exact12, g, min(g, last), P, a, tmin, behind_ok, best_t, best_i);
-        if (d1 >= 0.0f) exact_prim_test(exact12, g + 1, min(g + 1, last), P, a, tmin, behind_ok, best_t, best_i);
-        if (d2 >= 0.0f) exact_prim_test(exact12, g + 2, min(g + 2, last), P, a, tmin, behind_ok, best_t, best_i);
-        if (d3 >= 0.0f) exact_prim_test(exact12, g + 3, min(g + 3, last), P, a, tmin, behind_ok, best_t, best_i);
+        if (d0 >= 0.0f) exact_prim_test<double>(exact12, g, min(g, last), P, a, tmin, behind_ok, best_t, best_i);
+        if (d1 >= 0.0f) exact_prim_test<double>(exact12, g + 1, min(g + 1, last), P, a, tmin, behind_ok, best_t, best_i);
+        if (d2 >= 0.0f) exact_prim_test<double>(exact12, g + 2, min(g + 2, last), P, a, tmin, behind_ok, best_t, best_i);
+        if (d3 >= 0.0f) exact_prim_test<double>(exact12, g + 3, min(g + 3, last), P, a, tmin, behind_ok, best_t, best_i);
     }
 }
 
@@ -525,32 +528,37 @@ __device__ inline void scan_all_cull(SceneRef sc, const Path<double> &P, double 
 #define RTMI_BVH_STACK 32
 #endif
 
-__device__ inline void sphere_roots_any_order(double bq, double cq, double disc, double a, double tmin, bool behind_ok, double &best_t, int &best_i, int idx) {
-    if (behind_ok && bq > 0.0 && cq > 0.0) return;
-    const double sq = ::sqrt(disc);
-    double t = (-bq - sq) / a;
+template <typename R>
+__device__ inline void sphere_roots_any_order(R bq, R cq, R disc, R a, R tmin, bool behind_ok, R &best_t, int &best_i, int idx) {
+    if (behind_ok && bq > R(0) && cq > R(0)) return;
+    const R sq = Real<R>::sqrt_(disc);
+    R t = (-bq - sq) / a;
     if (!(t > tmin)) t = (-bq + sq) / a;
     if ((t > tmin) && ((t < best_t) || (t == best_t && idx < best_i))) { best_t = t; best_i = idx; }
 }
 
-// exact test of the primitive of leaf code `code` (per-lane: vector loads; a static sphere needs only its first 32 bytes)
-__device__ inline void exact_prim_test_lane(const double *exact12, int code, const Path<double> &P, double a, double tmin, bool behind_ok,
-                                            double &best_t, int &best_i) {
+// exact test of the primitive of leaf code `code` (per-lane: vector loads; a static sphere needs only its first 32 bytes).
+// RTMI_F32 reads the same FP64 records and rounds them to float exactly as the flat float scan does: centre (float)c,
+// r*r = one float multiply of (float)r (record slot 10), MovingSphere centre lerped in float.
+template <typename R>
+__device__ inline void exact_prim_test_lane(const double *exact12, int code, const Path<R> &P, R a, R tmin, bool behind_ok, R &best_t, int &best_i) {
     const int bits = ~code;
     const int idx = bits & 0x3fffffff;
     const double2 *g = reinterpret_cast<const double2 *>(exact12 + (size_t)idx * 12);
     const double2 g0 = g[0], g1 = g[1];
-    Prim4<double> s;
-    s.cx = g0.x; s.cy = g0.y; s.cz = g1.x; s.r2 = g1.y;
+    Prim4<R> s;
+    s.cx = (R)g0.x; s.cy = (R)g0.y; s.cz = (R)g1.x;
+    if (sizeof(R) == sizeof(double)) s.r2 = (R)g1.y;
+    else { const R rad = (R)g[5].x; s.r2 = rad * rad; }
     if (bits & 0x40000000) { // MovingSphere
         const double2 g2 = g[2], g3 = g[3], g4 = g[4];
-        const double t0 = g3.y, t1 = g4.x;
-        const double f = (P.time - t0) / (t1 - t0), omf = 1.0 - f;
-        s.cx = g0.x * omf + g2.x * f; s.cy = g0.y * omf + g2.y * f; s.cz = g1.x * omf + g3.x * f;
+        const R t0 = (R)g3.y, t1 = (R)g4.x;
+        const R f = (P.time - t0) / (t1 - t0), omf = R(1.0) - f;
+        s.cx = (R)g0.x * omf + (R)g2.x * f; s.cy = (R)g0.y * omf + (R)g2.y * f; s.cz = (R)g1.x * omf + (R)g3.x * f;
     }
-    double bq, cq, disc;
+    R bq, cq, disc;
     sphere_test(s, P, a, bq, cq, disc);
-    if (disc >= 0.0) sphere_roots_any_order(bq, cq, disc, a, tmin, behind_ok, best_t, best_i, idx);
+    if (disc >= R(0)) sphere_roots_any_order<R>(bq, cq, disc, a, tmin, behind_ok, best_t, best_i, idx);
 }
 
 // Conservative slab test in float, FMA form: t = plane * inv_d + (-o * inv_d).  Error budget: the rounding of
@@ -581,7 +589,8 @@ __device__ inline float float_up(double x) { // smallest float >= x (x finite, |
 }
 
 // what the float traversal needs to know about a ray; ok = false: take the exact flat scan instead
-__device__ inline BvhRay make_bvh_ray(SceneRef sc, const Path<double> &P, double a, double tmin) {
+template <typename R>
+__device__ inline BvhRay make_bvh_ray(SceneRef sc, const Path<R> &P, R a, R tmin) {
     BvhRay r;
     const float ox = (float)P.ox, oy = (float)P.oy, oz = (float)P.oz;
     const float dx = (float)P.dx, dy = (float)P.dy, dz = (float)P.dz;
@@ -589,18 +598,25 @@ __device__ inline BvhRay make_bvh_ray(SceneRef sc, const Path<double> &P, double
     const float omax = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
     // not boundable in float: non-finite values, a vanishing direction component (1/d would overflow), absurd magnitudes
     r.ok = (omax < 1e15f) && (dmax < 1e15f) && (dmax > 1e-15f) && (fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)) >= 1e-12f * dmax) &&
-           (a > 1e-30) && (a < 1e30) && (tmin > -1e30) && (tmin < 1e30) && (sc.bvh_obound >= 0.0f);
+           (a > R(1e-30)) && (a < R(1e30)) && (tmin > R(-1e30)) && (tmin < R(1e30)) && (sc.bvh_obound >= 0.0f);
     r.far = omax > sc.bvh_obound;
     r.time_ok = (P.time >= sc.cull_t_lo) && (P.time <= sc.cull_t_hi); // else the MovingSphere boxes do not bound this ray's spheres
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     const float cx = -ox * ix, cy = -oy * iy, cz = -oz * iz;
-    const float e = r.far ? omax * (1.0001f / 2097152.0f) : 0.0f;
+    // RTMI_F32: the boxes must also catch what the FLOAT sphere test calls a hit.  (a) The float spheres (rounded centres, float
+    // r*r, float lerp) may stick out of the boxes built from the FP64 geometry by a few 2^-24 |c|: 2^-20 of the larger of |o|
+    // and the scene bound.  (b) The float discriminant b^2 - a q carries an absolute error of up to ~40u a(|oc|^2 + r^2)
+    // (u = 2^-24), so the test can report a hit for a line that passes the centre at p with p^2 <= r^2 + 40u(|oc|^2 + r^2), i.e.
+    // up to 1.55e-3 sqrt(|oc|^2 + r^2) outside the sphere; with |oc| <= sqrt(3)(|o|_inf + cbound) and r <= cbound (cbound = the
+    // largest coordinate of any box in the tree) that is < 3.1e-3 (|o|_inf + cbound): every plane moves out by 4e-3 of that.
+    const float e = sizeof(R) == sizeof(float) ? fmaxf(omax, sc.bvh_obound) * (1.0001f / 1048576.0f) + 4.0e-3f * (omax + sc.bvh_cbound)
+                                               : (r.far ? omax * (1.0001f / 2097152.0f) : 0.0f);
     // signed slack: the plane x = lo is the entry plane when inv >= 0 (entry distances are lowered, exit distances raised)
     const float ex = e * ix, ey = e * iy, ez = e * iz; // = e |inv| * sign(inv)
     r.ixy = v2f{ix, iy}; r.izz = v2f{iz, iz};
     r.clxy = v2f{cx - ex, cy - ey}; r.chxy = v2f{cx + ex, cy + ey};
     r.czz = v2f{cz - ez, cz + ez};
-    r.tmin_lo = r.ok ? -float_up(-tmin) : 0.0f;
+    r.tmin_lo = r.ok ? -float_up(-(double)tmin) : 0.0f;
     return r;
 }
 
@@ -655,23 +671,25 @@ __device__ inline void bvh_traverse(SceneRef sc, int *stack, const BvhRay &r, Le
     }
 }
 
-__device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, double &best_t, int &best_i) {
-    const bool behind_ok = tmin >= 0.0;
+// flat(): the exact flat scan of the same precision, for rays the float boxes cannot bound
+template <typename R, typename Flat>
+__device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, R tmin, R &best_t, int &best_i, Flat flat) {
+    const bool behind_ok = tmin >= R(0);
     const double *exact12 = sc.exact12;
-    const BvhRay r = make_bvh_ray(sc, P, a, tmin);
+    const BvhRay r = make_bvh_ray<R>(sc, P, a, tmin);
     if (!r.ok) { // rays the float traversal cannot bound take the exact flat scan (all primitives, original order) instead
-        scan_all_cull(sc, P, a, tmin, best_t, best_i);
+        flat();
         return;
     }
     // 1. the big primitives (sky dome, ground, ...): exact test, ascending Hitlist index
-    for (int k = 0; k < sc.n_big; ++k) exact_prim_test(exact12, sc.big_idx[k], sc.big_idx[k], P, a, tmin, behind_ok, best_t, best_i);
+    for (int k = 0; k < sc.n_big; ++k) exact_prim_test<R>(exact12, sc.big_idx[k], sc.big_idx[k], P, a, tmin, behind_ok, best_t, best_i);
     // 2. the tree
-    auto leaf = [&](int code) { exact_prim_test_lane(exact12, code, P, a, tmin, behind_ok, best_t, best_i); };
-    auto best = [&]() { return best_t < 3.0e38 ? float_up(best_t) : 3.4028235e38f; };
+    auto leaf = [&](int code) { exact_prim_test_lane<R>(exact12, code, P, a, tmin, behind_ok, best_t, best_i); };
+    auto best = [&]() { return best_t < R(3.0e38) ? float_up((double)best_t) : 3.4028235e38f; };
     bvh_traverse(sc, stack, r, leaf, best);
     // 3. a ray outside the shutter interval: the MovingSphere boxes were built for [t_lo, t_hi], so test every moving sphere exactly
     if (!r.time_ok)
-        for (int k = 0; k < sc.n_moving_all; ++k) exact_prim_test_lane(exact12, ~(sc.moving_all[k] | 0x40000000), P, a, tmin, behind_ok, best_t, best_i);
+        for (int k = 0; k < sc.n_moving_all; ++k) exact_prim_test_lane<R>(exact12, ~(sc.moving_all[k] | 0x40000000), P, a, tmin, behind_ok, best_t, best_i);
 }
 
 // ==== section 8(f3): RectXY/XZ/YZ (hitable.clj:269-363), Triangle (548-571), FlipNormals (375-381), Translate (391-396),

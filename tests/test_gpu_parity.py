@@ -340,6 +340,31 @@ def test_bvh_accel_is_bit_identical(oracle, cover11, cover11_moving):
         ctx.close()
 
 
+def test_f32_bvh_is_bit_identical_to_f32_flat(oracle_f32, cover11, cover11_moving):
+    """RTMI_F32 with RTMI_ACCEL_BVH: float leaves behind the same float boxes (plus a per-ray slack for the rounding of the float
+    spheres) -- the closest hit, images and counters of the float flat scan, bit for bit"""
+    for sc in (cover11, cover11_moving, r.scene.make_random_scene(64, 32, 50, True)):
+        f = fl.flatten(sc)
+        ctx = core.Context(0)
+        ds = core.DeviceScene(f, ctx=ctx)
+        rays = np.concatenate([random_rays(20000, 18), tangent_rays(f, 60000, 19)])
+        far = random_rays(5000, 20); far[:, :3] *= 1.0e4; far[:, 6] = 7.5  # far origins, times outside the shutter
+        axis = rays[:3000].copy(); axis[:, 4] = 0.0
+        rays = np.concatenate([rays, far, axis])
+        ctx.set_option("accel", 0)
+        flat = ds.probe_hit(rays, precision="f32")
+        img_flat = ds.render(96, 48, 6, precision="f32")
+        ctx.set_option("accel", 1)
+        bvh = ds.probe_hit(rays, precision="f32")
+        img_bvh = ds.render(96, 48, 6, precision="f32")
+        assert np.array_equal(flat, bvh)
+        for a, b in zip(img_flat, img_bvh):
+            assert np.array_equal(a, b)
+        assert np.array_equal(bvh[::7, :9], oracle_f32.probe_hit(f, rays[::7])[:, :9])
+        ds.close()
+        ctx.close()
+
+
 def test_bvh_far_origins_and_out_of_shutter_times(oracle, cover11_moving):
     """rays the host-side box inflation does not cover take their own slab slack (origins up to 10^6 scene radii away), and
     rays whose time lies outside the camera's shutter interval test every MovingSphere exhaustively: both must stay exact"""
