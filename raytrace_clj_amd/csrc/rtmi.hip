@@ -684,7 +684,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
 
 // ---- RTMI_ACCEL_BVH host build ----------------------------------------------------------------------------------------
 // Binned-SAH binary BVH over the primitives' boxes, one primitive per leaf, each node carrying its two children's boxes
-// (one 64-byte fetch per step).  Boxes are FLOAT, rounded outward and inflated by 2^-22 * obound (see slab_hit): the
+// (one 64-byte fetch per step).  Boxes are FLOAT, rounded outward and inflated by 2^-21 * obound (see slab_hit): the
 // traversal is only a conservative filter in front of the exact FP64 sphere test, so the tree's shape affects speed, never
 // results.  Primitives whose radius is a large fraction of the scene (sky dome, ground) are kept out of the tree.
 struct BvhBox { double lo[3], hi[3]; };
@@ -836,7 +836,7 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
         if (ext >= 0.25 * obound && d.n_big < 16) d.big_idx[d.n_big++] = it.idx; // ascending index order
         else B.items.push_back(it);
     }
-    B.delta = obound * (1.0 / 4194304.0); // 2^-22 * obound
+    B.delta = obound * (1.0 / 2097152.0); // 2^-21 * obound
     B.moving.assign((size_t)std::max(n_prims, 1), 0);
     for (int i = 0; i < n_prims; ++i) B.moving[(size_t)i] = prim_kind[i] == RTMI_PRIM_MOVING;
     d.bvh_obound = f_down(obound);

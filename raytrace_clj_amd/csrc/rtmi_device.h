@@ -34,7 +34,7 @@ struct DevScene {
     int bvh_root;            // child code: >= 0 byte offset of the node record, < 0 = ~(original primitive index | moving << 30), 0x7fffffff = empty
     int n_big;               // primitives too large to bound usefully (sky dome, ground): always tested exactly
     int big_idx[16];
-    float bvh_obound;        // rays starting outside [-obound, obound]^3 move every box plane out by 2^-21 |o| themselves
+    float bvh_obound;        // rays starting outside [-obound, obound]^3 move every box plane out by 2^-20 |o| themselves
     float bvh_cbound;        // largest |coordinate| of the boxes in the tree (the big primitives are outside it)
     int n_moving_all;        // all MovingSphere world primitives (tested exhaustively for rays outside the shutter interval)
     const int *moving_all;
@@ -561,14 +561,18 @@ __device__ inline void exact_prim_test_lane(const double *exact12, int code, con
     if (disc >= R(0)) sphere_roots_any_order<R>(bq, cq, disc, a, tmin, behind_ok, best_t, best_i, idx);
 }
 
-// Conservative slab test in float, FMA form: t = plane * inv_d + (-o * inv_d).  Error budget: the rounding of
-// c = fl(-o_f * inv) and of the fma are each equivalent to moving the plane by <= 2^-24 |o| (plus a relative 2u on t), and
-// |fl32(o) - o| <= 2^-24 |o|; the box planes were rounded outward and inflated by 2^-22 * obound >= 4 * 2^-24 |o| on the
-// host, which covers all three for every ray with |o| <= obound.  A ray that starts OUTSIDE the scene bound (far: e.g.
-// after scattering in a scene-sized ConstantMedium) moves every plane outward by its own e = 2^-21 |o|_inf instead: the slack
-// e |inv| is folded into the additive constant per plane (c_lo for the planes x = lo, c_hi for x = hi; which of the two is
-// the entry plane is the sign of inv), one more rounding of the same size, hence 2^-21.  The remaining relative error (<= 4u
-// with the rounding of inv) is absorbed by lowering the entry distance and raising the exit distance by 8u before comparing.
+// Conservative slab test in float, FMA form: t = plane * inv_d + (-o * inv_d).  What the boxes must absorb, in units of
+// U = 2^-24 * obound (obound >= |o|_inf, |c|_inf, r for every ray that starts inside the scene bound):
+//   * |fl32(o) - o|, the rounding of c = fl(-o_f * inv) and the rounding of the fma: each equivalent to moving a plane by <= 1 U;
+//   * the exact test's own "phantom" zone: the FP64 discriminant b^2 - a q carries an absolute error of up to ~40 u64 a (|oc|^2 +
+//     r^2), so it can report a hit for a line passing the centre at p with p - r <= sqrt(40 u64 (|oc|^2 + r^2)) = 6.7e-8 * sqrt(13)
+//     * obound = 4 U in the worst case (origin and sphere in opposite corners);
+// together <= 7 U: the host rounds the box planes outward and inflates them by 2^-21 * obound = 8 U.  A ray that starts OUTSIDE
+// the scene bound (far: e.g. after scattering in a scene-sized ConstantMedium) moves every plane outward by its own
+// e = 2^-20 |o|_inf instead (|oc| <= 2 sqrt(3) |o|_inf there, plus one more rounding): the slack e |inv| is folded into the additive
+// constant per plane (c_lo for the planes x = lo, c_hi for x = hi; which of the two is the entry plane is the sign of inv).
+// The remaining relative error on t (<= 4u with the rounding of inv) is absorbed by lowering the entry distance and raising the
+// exit distance by 8u before comparing.
 // Both children of a node are tested together; the x/y planes go through packed FMAs (v_pk_fma_f32), z as (lo, hi) pairs.
 typedef float v2f __attribute__((ext_vector_type(2)));
 struct BvhRay { v2f ixy, izz, clxy, chxy, czz; float tmin_lo; bool ok, far, time_ok; };
@@ -610,7 +614,7 @@ __device__ inline BvhRay make_bvh_ray(SceneRef sc, const Path<R> &P, R a, R tmin
     // up to 1.55e-3 sqrt(|oc|^2 + r^2) outside the sphere; with |oc| <= sqrt(3)(|o|_inf + cbound) and r <= cbound (cbound = the
     // largest coordinate of any box in the tree) that is < 3.1e-3 (|o|_inf + cbound): every plane moves out by 4e-3 of that.
     const float e = sizeof(R) == sizeof(float) ? fmaxf(omax, sc.bvh_obound) * (1.0001f / 1048576.0f) + 4.0e-3f * (omax + sc.bvh_cbound)
-                                               : (r.far ? omax * (1.0001f / 2097152.0f) : 0.0f);
+                                               : (r.far ? omax * (1.0001f / 1048576.0f) : 0.0f);
     // signed slack: the plane x = lo is the entry plane when inv >= 0 (entry distances are lowered, exit distances raised)
     const float ex = e * ix, ey = e * iy, ez = e * iz; // = e |inv| * sign(inv)
     r.ixy = v2f{ix, iy}; r.izz = v2f{iz, iz};
