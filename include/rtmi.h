@@ -94,7 +94,12 @@ int rtmi_version(void);
 /* Binds a context to HIP device `device` (one process per GPU: pass LOCAL_RANK). */
 int rtmi_init(int device, uint32_t flags, rtmi_ctx **out_ctx);
 int rtmi_shutdown(rtmi_ctx *ctx);
-/* knobs: "blocks_per_cu" (int), "workspace_bytes" (sample-buffer budget), "accel" (RTMI_ACCEL_*) */
+/* knobs: "accel" (RTMI_ACCEL_*), "workspace_bytes" (sample-buffer budget: a frame is rendered in as many sample passes as
+ * it takes), "blocks_per_cu" (cap on resident trace workgroups per CU; the launch never exceeds what stays resident),
+ * "scan_variant" (flat scan: 0 LDS literal, 1 LDS pipelined, 2 scalar cache, 3 scalar cache + FP32 cull = default),
+ * "lds_tile_bytes" (LDS variants), "timing" (0/1 = RTMI_FLAG_TIMING).
+ * A context owns its workspace and work queue and is not re-entrant; for several frames in flight on one GPU use one context
+ * (and one stream) per frame slot. */
 int rtmi_set_option(rtmi_ctx *ctx, const char *name, int64_t value);
 int rtmi_device_info(rtmi_ctx *ctx, int32_t *compute_units, int32_t *lds_bytes_per_cu, int64_t *hbm_bytes, char *arch, int32_t arch_len);
 
