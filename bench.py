@@ -139,7 +139,7 @@ def main():
         """time `steps` steps of the path with the given acceleration structure on pipeline `pl`; returns the result fields"""
         pl.set_option("accel", 1 if accel == "bvh" else 0)
         tr = pl.slots[0][2]
-        for _ in range(warmup):
+        for _ in range(max(warmup, len(pl.slots))):  # every slot allocates its sample workspace on its first frame: never in the timed region
             pl.step(ns, precision=args.precision)
         barrier()
         pl.last_trace_ms()  # reset the event window

@@ -861,6 +861,51 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
             B.nodes.clear();
         }
     }
+    d.bvh_node16 = 0;
+    if (d.bvh_root != RTMI_BVH_EMPTY) { // 32-byte records (Node16) when rounding the planes to half costs little: 12 halves + 2 child codes
+        auto half_bits = [](float x, bool up) {
+            _Float16 h = (_Float16)x;
+            uint16_t b; std::memcpy(&b, &h, 2);
+            const float back = (float)h;
+            if (up ? (back < x) : (back > x)) { // step to the next half outward
+                if (b == 0x0000 || b == 0x8000) b = up ? 0x0001 : 0x8001;
+                else if ((b & 0x8000) ? !up : up) b += 1; // away from zero
+                else b -= 1;                               // towards zero
+            }
+            return b;
+        };
+        auto half_val = [](uint16_t b) { _Float16 h; std::memcpy(&h, &b, 2); return (double)(float)h; };
+        std::vector<float> out(B.nodes.size() / 2, 0.0f);
+        double area32 = 0.0, area16 = 0.0;
+        for (size_t n = 0; n < B.nodes.size() / 16; ++n) {
+            const float *q = &B.nodes[n * 16];
+            uint16_t h[12];
+            for (int side = 0; side < 2; ++side) {
+                const float lo[3] = {q[side * 4], q[side * 4 + 1], q[8 + side * 2]}, hi[3] = {q[side * 4 + 2], q[side * 4 + 3], q[8 + side * 2 + 1]};
+                double e32[3], e16[3];
+                for (int k = 0; k < 3; ++k) {
+                    h[side * 6 + k * 2] = half_bits(lo[k], false); h[side * 6 + k * 2 + 1] = half_bits(hi[k], true);
+                    e32[k] = (double)hi[k] - lo[k]; e16[k] = half_val(h[side * 6 + k * 2 + 1]) - half_val(h[side * 6 + k * 2]);
+                }
+                if (e32[0] >= 0 && std::isfinite(e32[0] + e32[1] + e32[2])) { // (the lone primitive's empty sibling is +inf / -inf)
+                    area32 += e32[0] * e32[1] + e32[1] * e32[2] + e32[2] * e32[0];
+                    area16 += std::isfinite(e16[0] + e16[1] + e16[2]) ? e16[0] * e16[1] + e16[1] * e16[2] + e16[2] * e16[0] : INFINITY;
+                }
+            }
+            int c[2];
+            std::memcpy(c, &q[12], 8);
+            for (int k = 0; k < 2; ++k) if (c[k] >= 0 && c[k] != RTMI_BVH_EMPTY) c[k] /= 2; // byte offsets of 32-byte records
+            std::memcpy(reinterpret_cast<char *>(&out[n * 8]), h, 24);
+            std::memcpy(reinterpret_cast<char *>(&out[n * 8]) + 24, c, 8);
+        }
+        const char *force = std::getenv("RTMI_NODE16"); // "0" / "1": override the choice (tests)
+        const bool use16 = force ? force[0] == '1' : (area16 <= 1.25 * area32);
+        if (use16) {
+            d.bvh_node16 = 1;
+            d.bvh_root = d.bvh_root >= 0 ? d.bvh_root / 2 : d.bvh_root;
+            return out;
+        }
+    }
     return B.nodes;
 }
 

@@ -34,6 +34,7 @@ struct DevScene {
     int bvh_root;            // child code: >= 0 byte offset of the node record, < 0 = ~(original primitive index | moving << 30), 0x7fffffff = empty
     int n_big;               // primitives too large to bound usefully (sky dome, ground): always tested exactly
     int big_idx[16];
+    int bvh_node16;          // node records: 1 = Node16 (32 bytes, half planes), 0 = 16 floats
     float bvh_obound;        // rays starting outside [-obound, obound]^3 move every box plane out by 2^-20 |o| themselves
     float bvh_cbound;        // largest |coordinate| of the boxes in the tree (the big primitives are outside it)
     int n_moving_all;        // all MovingSphere world primitives (tested exhaustively for rays outside the shutter interval)
@@ -576,6 +577,19 @@ __device__ inline void exact_prim_test_lane(const double *exact12, int code, con
 // Both children of a node are tested together; the x/y planes go through packed FMAs (v_pk_fma_f32), z as (lo, hi) pairs.
 typedef float v2f __attribute__((ext_vector_type(2)));
 struct BvhRay { v2f ixy, izz, clxy, chxy, czz; float tmin_lo; bool ok, far, time_ok; };
+// 32-byte node format (DevScene::bvh_node16): the planes as IEEE half, rounded outward on the host, consumed by v_fma_mix_f32
+// without a conversion instruction: half the bytes per step through the texture-address / L1 path (C2 -3 %, C3 -6 %).  The host
+// picks it when rounding to half grows the boxes' total area by less than a quarter (coordinates small against object sizes).
+struct __attribute__((aligned(16))) Node16 { _Float16 p[12]; int cl, cr; }; // l: lo.x hi.x lo.y hi.y lo.z hi.z, r: the same, left, right
+__device__ inline bool slab_hit6(float ax, float bx, float ay, float by, float az, float bz, const float tmin_lo, const float best_hi, float &tnear) {
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float ku = 8.0f * 5.9604645e-08f;
+    tn = fmaf(-ku, fabsf(tn), tn);
+    tf = fmaf(ku, fabsf(tf), tf);
+    tnear = tn;
+    return (tn <= tf) && (tf >= tmin_lo) && (tn <= best_hi);
+}
 __device__ inline bool slab_hit(const v2f a, const v2f b, const v2f z, const float tmin_lo, const float best_hi, float &tnear) {
     float tn = fmaxf(fmaxf(fminf(a.x, b.x), fminf(a.y, b.y)), fminf(z.x, z.y));
     float tf = fminf(fminf(fmaxf(a.x, b.x), fmaxf(a.y, b.y)), fmaxf(z.x, z.y));
@@ -636,8 +650,8 @@ __device__ inline unsigned long long stamp_now() {
     return t;
 }
 #endif
-template <typename Leaf, typename BestHi>
-__device__ inline void bvh_traverse(SceneRef sc, int *stack, const BvhRay &r, Leaf leaf, BestHi best) {
+template <bool NODE16, typename Leaf, typename BestHi>
+__device__ inline void bvh_traverse_fmt(SceneRef sc, int *stack, const BvhRay &r, Leaf leaf, BestHi best) {
     int node = sc.bvh_root; // inner node: byte offset of its record (>= 0); leaf: ~(primitive | moving << 30) (< 0)
     if (node == RTMI_BVH_EMPTY) return;
     const int stride = blockDim.x;
@@ -646,16 +660,28 @@ __device__ inline void bvh_traverse(SceneRef sc, int *stack, const BvhRay &r, Le
     const char *nodes = reinterpret_cast<const char *>(sc.bvh_nodes);
     float best_hi = best();
     while (node != RTMI_BVH_EMPTY) {
-        while (node >= 0 && node != RTMI_BVH_EMPTY) { // inner node: both child boxes come with it (one 64-byte record)
-            // record: l.lo.xy l.hi.xy | r.lo.xy r.hi.xy | l.lo.z l.hi.z r.lo.z r.hi.z | left, right
-            const float4 *q = reinterpret_cast<const float4 *>(nodes + (unsigned)node);
-            const float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
+        while (node >= 0 && node != RTMI_BVH_EMPTY) { // inner node: both child boxes come with it (one record)
             float tl, tr;
-            const bool hl = slab_hit(__builtin_elementwise_fma(v2f{n0.x, n0.y}, r.ixy, r.clxy), __builtin_elementwise_fma(v2f{n0.z, n0.w}, r.ixy, r.chxy),
-                                     __builtin_elementwise_fma(v2f{n2.x, n2.y}, r.izz, r.czz), r.tmin_lo, best_hi, tl);
-            const bool hr = slab_hit(__builtin_elementwise_fma(v2f{n1.x, n1.y}, r.ixy, r.clxy), __builtin_elementwise_fma(v2f{n1.z, n1.w}, r.ixy, r.chxy),
-                                     __builtin_elementwise_fma(v2f{n2.z, n2.w}, r.izz, r.czz), r.tmin_lo, best_hi, tr);
-            const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
+            bool hl, hr;
+            int cl, cr;
+            if (NODE16) {
+                const Node16 nd = *reinterpret_cast<const Node16 *>(nodes + (unsigned)node);
+                hl = slab_hit6(fmaf((float)nd.p[0], r.ixy.x, r.clxy.x), fmaf((float)nd.p[1], r.ixy.x, r.chxy.x), fmaf((float)nd.p[2], r.ixy.y, r.clxy.y),
+                               fmaf((float)nd.p[3], r.ixy.y, r.chxy.y), fmaf((float)nd.p[4], r.izz.x, r.czz.x), fmaf((float)nd.p[5], r.izz.x, r.czz.y),
+                               r.tmin_lo, best_hi, tl);
+                hr = slab_hit6(fmaf((float)nd.p[6], r.ixy.x, r.clxy.x), fmaf((float)nd.p[7], r.ixy.x, r.chxy.x), fmaf((float)nd.p[8], r.ixy.y, r.clxy.y),
+                               fmaf((float)nd.p[9], r.ixy.y, r.chxy.y), fmaf((float)nd.p[10], r.izz.x, r.czz.x), fmaf((float)nd.p[11], r.izz.x, r.czz.y),
+                               r.tmin_lo, best_hi, tr);
+                cl = nd.cl; cr = nd.cr;
+            } else { // 64-byte record: l.lo.xy l.hi.xy | r.lo.xy r.hi.xy | l.lo.z l.hi.z r.lo.z r.hi.z | left, right
+                const float4 *q = reinterpret_cast<const float4 *>(nodes + (unsigned)node);
+                const float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
+                hl = slab_hit(__builtin_elementwise_fma(v2f{n0.x, n0.y}, r.ixy, r.clxy), __builtin_elementwise_fma(v2f{n0.z, n0.w}, r.ixy, r.chxy),
+                              __builtin_elementwise_fma(v2f{n2.x, n2.y}, r.izz, r.czz), r.tmin_lo, best_hi, tl);
+                hr = slab_hit(__builtin_elementwise_fma(v2f{n1.x, n1.y}, r.ixy, r.clxy), __builtin_elementwise_fma(v2f{n1.z, n1.w}, r.ixy, r.chxy),
+                              __builtin_elementwise_fma(v2f{n2.z, n2.w}, r.izz, r.czz), r.tmin_lo, best_hi, tr);
+                cl = __float_as_int(n3.x); cr = __float_as_int(n3.y);
+            }
             if (hl && hr) {
                 const bool left_first = tl <= tr;
                 *top = left_first ? cr : cl;
@@ -673,6 +699,13 @@ __device__ inline void bvh_traverse(SceneRef sc, int *stack, const BvhRay &r, Le
             else node = RTMI_BVH_EMPTY;
         }
     }
+}
+
+// one loop per record format (a format test inside the loop costs 5 %)
+template <typename Leaf, typename BestHi>
+__device__ inline void bvh_traverse(SceneRef sc, int *stack, const BvhRay &r, Leaf leaf, BestHi best) {
+    if (sc.bvh_node16) bvh_traverse_fmt<true>(sc, stack, r, leaf, best);
+    else bvh_traverse_fmt<false>(sc, stack, r, leaf, best);
 }
 
 // flat(): the exact flat scan of the same precision, for rays the float boxes cannot bound

@@ -340,6 +340,42 @@ def test_bvh_accel_is_bit_identical(oracle, cover11, cover11_moving):
         ctx.close()
 
 
+def test_bvh_node_formats_agree(cover11_moving, monkeypatch):
+    """the tree is uploaded as 32-byte records (planes in half, rounded outward) when that inflates the boxes little, else as 64-byte
+    float records; either way it is only a conservative filter: same hits as the flat scan, bit for bit"""
+    f = fl.flatten(cover11_moving)
+    rays = np.concatenate([random_rays(20000, 28), tangent_rays(f, 40000, 29)])
+    # a scene far from the origin: half cannot resolve radius-0.2 spheres at |x| ~ 3000, so the choice falls on float records
+    far_items = [r.hitable.sphere(center=vec3(3000 + 0.7 * i, 0.2, -2500 + 0.9 * (i % 7)), radius=0.2, material=MATERIAL) for i in range(60)]
+    far_sc = {"camera": r.camera.thin_lens_camera(lookfrom=vec3(3010, 3, -2490), lookat=vec3(3020, 0, -2498), vup=vec3(0, 1, 0), vfov=40, aspect=2.0,
+                                                   aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0),
+              "world": r.hitable.hitlist(items=far_items)}
+    far_f = fl.flatten(far_sc)
+    far_rays = np.concatenate([tangent_rays(far_f, 20000, 30), random_rays(5000, 31)])
+    results = {}
+    for fmt in ("0", "1", None):
+        if fmt is None:
+            monkeypatch.delenv("RTMI_NODE16", raising=False)
+        else:
+            monkeypatch.setenv("RTMI_NODE16", fmt)
+        for name, ff, rr in (("cover", f, rays), ("far", far_f, far_rays)):
+            ctx = core.Context(0)
+            ds = core.DeviceScene(ff, ctx=ctx)
+            ctx.set_option("accel", 0)
+            flat = ds.probe_hit(rr)
+            ctx.set_option("accel", 1)
+            bvh = ds.probe_hit(rr)
+            img = ds.render(64, 32, 4)
+            assert np.array_equal(flat, bvh), (fmt, name)
+            results[(fmt, name)] = img
+            ds.close(); ctx.close()
+    for name in ("cover", "far"):
+        for a, b in zip(results[("0", name)], results[("1", name)]):
+            assert np.array_equal(a, b)
+        for a, b in zip(results[("0", name)], results[(None, name)]):
+            assert np.array_equal(a, b)
+
+
 def test_f32_bvh_is_bit_identical_to_f32_flat(oracle_f32, cover11, cover11_moving):
     """RTMI_F32 with RTMI_ACCEL_BVH: float leaves behind the same float boxes (plus a per-ray slack for the rounding of the float
     spheres) -- the closest hit, images and counters of the float flat scan, bit for bit"""
