@@ -720,33 +720,41 @@ struct BvhBuilder {
         if (e - b == 1) return leaf_code(items[(size_t)b].idx);
         const int node = (int)(nodes.size() / 16);
         nodes.resize(nodes.size() + 16, 0.0f);
-        // split: binned SAH on the axis of largest centroid extent; median fallback (also beyond sah_depth, to bound the stack)
+        // split: binned SAH (32 bins) over all three axes, the cheapest split wins; median split on the longest axis as the fallback
+        // (also beyond sah_depth, to bound the stack)
         double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
         for (int i = b; i < e; ++i) for (int k = 0; k < 3; ++k) { clo[k] = std::min(clo[k], items[(size_t)i].cen[k]); chi[k] = std::max(chi[k], items[(size_t)i].cen[k]); }
         int axis = 0;
         for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
         int mid = (b + e) / 2;
-        const double ext = chi[axis] - clo[axis];
         bool done = false;
-        if (ext > 0 && depth < sah_depth && e - b > 2) {
-            const int NB = 16;
-            BvhBox bb[NB]; int cnt[NB];
-            for (int k = 0; k < NB; ++k) { bb[k] = box_empty(); cnt[k] = 0; }
-            auto bin_of = [&](const BvhItem &it) { int q = (int)((it.cen[axis] - clo[axis]) / ext * NB); return std::min(NB - 1, std::max(0, q)); };
-            for (int i = b; i < e; ++i) { const int q = bin_of(items[(size_t)i]); box_grow(bb[q], items[(size_t)i].b); cnt[q]++; }
-            double best = 1e300; int best_k = -1;
-            BvhBox right[NB]; int rc[NB];
-            BvhBox acc = box_empty(); int n = 0;
-            for (int k = NB - 1; k > 0; --k) { box_grow(acc, bb[k]); n += cnt[k]; right[k] = acc; rc[k] = n; }
-            acc = box_empty(); n = 0;
-            for (int k = 0; k < NB - 1; ++k) {
-                box_grow(acc, bb[k]); n += cnt[k];
-                if (n == 0 || rc[k + 1] == 0) continue;
-                const double cost = box_area(acc) * n + box_area(right[k + 1]) * rc[k + 1];
-                if (cost < best) { best = cost; best_k = k; }
+        if (depth < sah_depth && e - b > 2) {
+            const int NB = 32;
+            double best = 1e300; int best_k = -1, best_axis = -1;
+            for (int ax = 0; ax < 3; ++ax) {
+                const double ext = chi[ax] - clo[ax];
+                if (!(ext > 0)) continue;
+                BvhBox bb[NB]; int cnt[NB];
+                for (int k = 0; k < NB; ++k) { bb[k] = box_empty(); cnt[k] = 0; }
+                for (int i = b; i < e; ++i) {
+                    const int q = std::min(NB - 1, std::max(0, (int)((items[(size_t)i].cen[ax] - clo[ax]) / ext * NB)));
+                    box_grow(bb[q], items[(size_t)i].b); cnt[q]++;
+                }
+                BvhBox right[NB]; int rc[NB];
+                BvhBox acc = box_empty(); int n = 0;
+                for (int k = NB - 1; k > 0; --k) { box_grow(acc, bb[k]); n += cnt[k]; right[k] = acc; rc[k] = n; }
+                acc = box_empty(); n = 0;
+                for (int k = 0; k < NB - 1; ++k) {
+                    box_grow(acc, bb[k]); n += cnt[k];
+                    if (n == 0 || rc[k + 1] == 0) continue;
+                    const double cost = box_area(acc) * n + box_area(right[k + 1]) * rc[k + 1];
+                    if (cost < best) { best = cost; best_k = k; best_axis = ax; }
+                }
             }
             if (best_k >= 0) {
-                auto it = std::partition(items.begin() + b, items.begin() + e, [&](const BvhItem &x) { return bin_of(x) <= best_k; });
+                const double ext = chi[best_axis] - clo[best_axis], lo = clo[best_axis];
+                auto it = std::partition(items.begin() + b, items.begin() + e, [&](const BvhItem &x) {
+                    return std::min(NB - 1, std::max(0, (int)((x.cen[best_axis] - lo) / ext * NB))) <= best_k; });
                 mid = (int)(it - items.begin());
                 done = mid > b && mid < e;
             }
