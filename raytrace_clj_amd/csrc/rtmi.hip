@@ -1243,7 +1243,28 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     if (!rc) rc = upload(s, stat4_f, &d.stat4_f);
     if (!rc) rc = upload(s, mov_geom, &d.mov_geom);
     if (!rc) rc = upload(s, mov_orig, &d.mov_orig);
-    if (!rc) rc = upload(s, pk, &d.prim_kind);
+    { // device copy of prim_kind: + RTMI_PRIM_NEEDS_UV where a UVSphere's material texture reads uv (texture.clj: UVGradient,
+      // ImageMap, through Checkerboard / FlipTexture children); Constant, Checkerboard itself and the Perlin family read p only
+        std::vector<char> uses((size_t)std::max(n_tex, 1), 0);
+        for (int pass = 0; pass <= n_tex; ++pass) // children may come after their parents: iterate to the fixed point
+            for (int t = 0; t < n_tex; ++t) {
+                const int k = tex_kind[t];
+                char u = (k == RTMI_TEX_UVGRADIENT || k == RTMI_TEX_IMAGE) ? 1 : 0;
+                if (k == RTMI_TEX_CHECKER || k == RTMI_TEX_FLIP_U || k == RTMI_TEX_FLIP_V)
+                    for (int c = 0; c < (k == RTMI_TEX_CHECKER ? 2 : 1); ++c) {
+                        const int ch = tex_child[2 * (size_t)t + c];
+                        if (ch >= 0 && ch < n_tex && uses[(size_t)ch]) u = 1;
+                    }
+                uses[(size_t)t] = u;
+            }
+        std::vector<int> pk_dev(pk);
+        for (int i = 0; i < n_prims; ++i)
+            if (pk[(size_t)i] == RTMI_PRIM_UVSPHERE) {
+                const int m = pm[(size_t)i], t = (m >= 0 && m < n_mats) ? mat_tex[m] : -1;
+                if (t < 0 || t >= n_tex || uses[(size_t)t]) pk_dev[(size_t)i] |= RTMI_PRIM_NEEDS_UV;
+            }
+        if (!rc) rc = upload(s, pk_dev, &d.prim_kind);
+    }
     if (!rc) rc = upload(s, pm, &d.prim_mat);
     if (!rc) rc = upload(s, mk, &d.mat_kind);
     if (!rc) rc = upload(s, mt, &d.mat_tex);

@@ -108,6 +108,17 @@ template <> struct Real<float> {
     __device__ static inline float pow_(float x, float y) { return ::powf(x, y); }
 };
 
+// x^5 for Schlick's approximation (shader.clj:69-74: (Math/pow (- 1.0 cosine) 5.0)).  Math/pow and the oracle's libm pow are
+// (almost always) correctly rounded; a generic device pow() is ~200 FP64 instructions and no closer.  Three double-double
+// products keep the error below 2^-100 before the final rounding, i.e. the correctly rounded power except for near-ties.
+__device__ inline double pow5(double x) {
+    const double h2 = x * x, l2 = ::fma(x, x, -h2);
+    const double h4 = h2 * h2, l4 = ::fma(h2, h2, -h4) + 2.0 * (h2 * l2);
+    const double h5 = h4 * x, l5 = ::fma(h4, x, -h5) + l4 * x;
+    return h5 + l5;
+}
+__device__ inline float pow5(float x) { const double d = (double)x, d2 = d * d; return (float)(d2 * d2 * d); } // 3 roundings at 2^-53, then one to float
+
 // ---- per-path state: the loop/recur state of `color` (core.clj:23) plus the sample's stream -------
 template <typename R> struct Path {
     R ox, oy, oz, dx, dy, dz, time; // ray map {:origin :direction :time}, util.clj:13-16
@@ -961,7 +972,10 @@ template <typename R> struct HitRec { R t, px, py, pz, nx, ny, nz, u, v; int ori
 // Rebuild the hit record of primitive `orig` (original Hitlist index) at parameter t: centre (hitable.clj:219-222 for moving
 // spheres), p = point-at-parameter (util.clj:18-22), normal = normalise(p - centre) (hitable.clj:194),
 // uv = get-sphere-uv for UVSphere (hitable.clj:128-139) else [0 0].
-template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path<R> &P, R t, int orig, HitRec<R> &h) {
+// `all_uv`: the probes report uv of every UVSphere hit; the trace kernel computes it (atan2 + asin) only where the hit material's
+// texture reads uv (bit RTMI_PRIM_NEEDS_UV of the device copy of prim_kind: e.g. not for a constant-colour sky dome).
+#define RTMI_PRIM_NEEDS_UV 32
+template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path<R> &P, R t, int orig, HitRec<R> &h, bool all_uv = true) {
     const double *g = sc.exact12 + (size_t)orig * 12;
     R cx = (R)g[0], cy = (R)g[1], cz = (R)g[2];
     h.orig = orig;
@@ -970,7 +984,8 @@ template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path
         const R f = (P.time - t0) / (t1 - t0), omf = R(1.0) - f;
         cx = (R)g[0] * omf + (R)g[4] * f; cy = (R)g[1] * omf + (R)g[5] * f; cz = (R)g[2] * omf + (R)g[6] * f;
     }
-    h.kind = sc.prim_kind[h.orig];
+    const int kind_flags = sc.prim_kind[h.orig];
+    h.kind = kind_flags & 15;
     h.mat = sc.prim_mat[h.orig];
     h.t = t;
     h.px = P.dx * t + P.ox; h.py = P.dy * t + P.oy; h.pz = P.dz * t + P.oz;
@@ -979,7 +994,7 @@ template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path
     if (len > R(0)) { const R inv = R(1.0) / len; nx = nx * inv; ny = ny * inv; nz = nz * inv; }
     h.nx = nx; h.ny = ny; h.nz = nz;
     h.u = R(0); h.v = R(0);
-    if (h.kind == RTMI_PRIM_UVSPHERE) {
+    if (h.kind == RTMI_PRIM_UVSPHERE && (all_uv || (kind_flags & RTMI_PRIM_NEEDS_UV))) {
         const R PI = Real<R>::pi();
         const R phi = Real<R>::atan2_(nz, nx);
         const R theta = Real<R>::asin_(ny);
@@ -1043,8 +1058,8 @@ __device__ inline void resolve_hit_ext(SceneRef sc, const Path<double> &P, doubl
     }
     h.px = px; h.py = py; h.pz = pz; h.nx = nx; h.ny = ny; h.nz = nz;
 }
-template <typename R, bool EXT> __device__ inline void resolve_any(SceneRef sc, const Path<R> &P, R t, int orig, HitRec<R> &h) { resolve_hit<R>(sc, P, t, orig, h); }
-template <> __device__ inline void resolve_any<double, true>(SceneRef sc, const Path<double> &P, double t, int orig, HitRec<double> &h) { resolve_hit_ext(sc, P, t, orig, h); }
+template <typename R, bool EXT> __device__ inline void resolve_any(SceneRef sc, const Path<R> &P, R t, int orig, HitRec<R> &h, bool all_uv = true) { resolve_hit<R>(sc, P, t, orig, h, all_uv); }
+template <> __device__ inline void resolve_any<double, true>(SceneRef sc, const Path<double> &P, double t, int orig, HitRec<double> &h, bool) { resolve_hit_ext(sc, P, t, orig, h); }
 
 // Shader.scatter + Shader.emitted for the hit record, and the atten/accum update of core.clj:27-39.
 // Returns true when the path continues (the `recur` of core.clj:30) with P holding the scattered ray.
@@ -1103,7 +1118,7 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
         if (disc > R(0)) {
             R r0 = (R(1.0) - ri) / (R(1.0) + ri);
             r0 = r0 * r0;
-            const R prob = r0 + (R(1.0) - r0) * Real<R>::pow_(R(1.0) - cosine, R(5.0));
+            const R prob = r0 + (R(1.0) - r0) * pow5(R(1.0) - cosine);
             if (!(next_uniform(P) < prob)) { // one draw, only when refraction is possible (shader.clj:91-93)
                 const R sq = Real<R>::sqrt_(disc);
                 sdx = eta * (ux - onx * dt) - onx * sq;
@@ -1135,7 +1150,7 @@ template <typename R, bool EXT = false>
 __device__ inline bool shade_segment(SceneRef sc, Path<R> &P, R t, int orig, SegLog *lg) {
     if (orig < 0) return false; // miss: (color) returns accum, core.clj:40-41
     HitRec<R> h;
-    resolve_any<R, EXT>(sc, P, t, orig, h);
+    resolve_any<R, EXT>(sc, P, t, orig, h, false);
     const bool scat = scatter_emit<R, EXT>(sc, P, h, nullptr);
     if (lg && lg->n < lg->max_seg) {
         double *q = lg->rec + (size_t)lg->n * RTMI_SEG_REC;
