@@ -38,11 +38,13 @@ constexpr int kBlock = 256;
 // Diagnostic build only (make stamps -> librtmi_stamps.so): s_memtime around the phases of a loop trip, summed per wave and
 // added to g_stamps[phase], printed to stderr after every render.  Never defined in the shipped library.
 #ifdef RTMI_STAMPS
-#define RTMI_STAMP_DECL unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = stamp_now(); const unsigned long long st_wg0 = real_now();
+#define RTMI_STAMP_DECL unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = stamp_now(); const unsigned long long st_wg0 = real_now(); \
+    if (lane == 0) for (int k_ = 0; k_ < 18; ++k_) g_st_sub[threadIdx.x >> 6][k_] = 0;
 #define RTMI_STAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = stamp_now(); st_acc[k] += n_ - st_t; st_t = n_; __builtin_amdgcn_sched_barrier(0); }
 __device__ unsigned long long g_wg_t[2][4096]; // s_memrealtime (100 MHz) at workgroup start / end
 __device__ inline unsigned long long real_now() { unsigned long long t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }
-#define RTMI_STAMP_FLUSH(cnt) if (lane == 0) { for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_stamps[k_], st_acc[k_]); } \
+#define RTMI_STAMP_FLUSH(cnt) if (lane == 0) { for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_stamps[k_], st_acc[k_]); \
+                                               for (int k_ = 8; k_ < 16; ++k_) atomicAdd(&g_stamps[k_], g_st_sub[threadIdx.x >> 6][k_]); } \
     __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4096) { g_wg_t[0][blockIdx.x] = st_wg0; g_wg_t[1][blockIdx.x] = real_now(); }
 #else
 #define RTMI_STAMP_DECL
@@ -168,10 +170,13 @@ __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per
 
 // core.clj:43-51: jittered (u, v) for sample s of pixel (i, j), then the camera ray.
 template <typename R> __device__ inline void start_sample(SceneRef sc, const TraceParams &tp, int i, int j, int s, Path<R> &P) {
+    RTMI_SUBSTAMP(-1)
     seed_stream(P, sample_key(tp.seed, (u64)j * (u64)tp.nx + (u64)i, (u64)s), 0u);
     const R u = ((R)(float)i + next_uniform(P)) / (R)tp.nx;
     const R v = ((R)(float)j + next_uniform(P)) / (R)tp.ny;
+    RTMI_SUBSTAMP(13)
     get_ray<R>(sc, u, v, P);
+    RTMI_SUBSTAMP(14)
     P.ar = P.ag = P.ab = R(1);
     P.cr = P.cg = P.cb = R(0);
     P.depth = tp.depth;
@@ -656,12 +661,12 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
     {
         const int grid_trace_dbg = c->last_grid;
         HIP_TRY(hipStreamSynchronize(st));
-        unsigned long long h[8] = {0}, z[8] = {0};
+        unsigned long long h[16] = {0}, z[16] = {0};
         HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)));
         unsigned long long h2[8] = {0};
         HIP_TRY(hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_stamps2), sizeof(h2)));
-        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps2), z, sizeof(z)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps2), z, sizeof(h2)));
         fprintf(stderr, "[stamps] bvh: inner ticks %.3g leaf ticks %.3g | inner trips %llu (lanes/trip %.1f) leaf trips %llu (lanes/trip %.1f) calls %llu\n",
                 (double)h2[0], (double)h2[1], h2[2], (double)h2[3] / (double)(h2[2] ? h2[2] : 1), h2[4], (double)h2[5] / (double)(h2[4] ? h2[4] : 1), h2[6]);
         {
@@ -675,8 +680,11 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
                     b[g / 2], b[g - 1], e[0], e[g / 10], e[g / 2], e[g * 9 / 10], e[g - 1], g);
         }
         double tot = 0; for (int k = 0; k < 6; ++k) tot += (double)h[k];
-        fprintf(stderr, "[stamps] refill %.1f%% intersect %.1f%% shade %.1f%% (3: %.1f%% 4: %.1f%%) loop %.1f%%  total %.3g wave-ticks\n", 100 * h[0] / tot,
-                100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, tot);
+        fprintf(stderr, "[stamps] refill %.1f%% intersect %.1f%% shade %.1f%% loop %.1f%%  total %.3g wave-ticks\n", 100 * h[0] / tot,
+                100 * h[1] / tot, 100 * h[2] / tot, 100 * h[5] / tot, tot);
+        fprintf(stderr, "[stamps] of the total: resolve_hit %.1f%% | scatter: |d| %.1f%% rand-in-unit-sphere %.1f%% directions %.1f%% texture %.1f%% | "
+                        "start_sample: key+uv %.1f%% get-ray %.1f%%\n", 100 * h[8] / tot, 100 * h[9] / tot, 100 * h[10] / tot, 100 * h[11] / tot,
+                100 * h[12] / tot, 100 * h[13] / tot, 100 * h[14] / tot);
     }
 #endif
     return RTMI_OK;

@@ -86,6 +86,21 @@ __host__ __device__ inline u64 sample_key(u64 seed, u64 pix, u64 s) {
 }
 __host__ __device__ inline u64 draw_bits(u64 key, u64 d) { return mix64(key + RTMI_GOLD * (d + 1)); }
 
+#ifdef RTMI_STAMPS // diagnostic build only (make stamps): sub-phase times of a wave, accumulated in LDS by its first active lane
+__shared__ unsigned long long g_st_sub[4][18]; // [wave][16] = last stamp
+__device__ inline void substamp(int k) {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    const int w = threadIdx.x >> 6;
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) {
+        if (k >= 0) g_st_sub[w][k] += t - g_st_sub[w][16];
+        g_st_sub[w][16] = t;
+    }
+}
+#define RTMI_SUBSTAMP(k) substamp(k);
+#else
+#define RTMI_SUBSTAMP(k)
+#endif
 template <typename R> struct Real;
 template <> struct Real<double> {
     __device__ static inline double uniform(u64 z) { return (double)(z >> 11) * (1.0 / 9007199254740992.0); }
@@ -654,7 +669,7 @@ __device__ inline BvhRay make_bvh_ray(SceneRef sc, const Path<R> &P, R a, R tmin
 // column per thread (stack[level * blockDim.x + tid]: conflict-free).  leaf(code) runs the exact test, best() returns the
 // current float upper bound of the closest t.
 #ifdef RTMI_STAMPS // diagnostic build only (make stamps)
-__device__ unsigned long long g_stamps[8], g_stamps2[8];
+__device__ unsigned long long g_stamps[16], g_stamps2[8];
 __device__ inline unsigned long long stamp_now() {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -1088,7 +1103,9 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
     }
     // phase 2 -- rand-in-unit-sphere: Lambertian (shader.clj:32) and Metal (shader.clj:53; drawn even when fuzz = 0)
     R rx = R(0), ry = R(0), rz = R(0);
+    RTMI_SUBSTAMP(9)
     if (is_lamb || is_metal || is_iso) rand_in_unit_sphere(P, rx, ry, rz);
+    RTMI_SUBSTAMP(10)
     // phase 3 -- directions
     if (is_lamb) { // shader.clj:29-34: target = (p + normal) + rand; dir = target - p
         const R tx = (px + nx) + rx, ty = (py + ny) + ry, tz = (pz + nz) + rz;
@@ -1128,6 +1145,7 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
         }
         scat = true;
     }
+    RTMI_SUBSTAMP(11)
     // phase 4 -- ONE texture evaluation: emitted of DiffuseLight (shader.clj:118-119) or the albedo of a successful
     // Lambertian / Metal scatter (shader.clj:34,57)
     if (is_light || is_lamb || is_iso || (is_metal && scat)) {
@@ -1136,6 +1154,7 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
         if (is_light) { P.cr = P.cr + P.ar * tr; P.cg = P.cg + P.ag * tg; P.cb = P.cb + P.ab * tb; } // core.clj:37-39
         else { atr = tr; atg = tg; atb = tb; }
     }
+    RTMI_SUBSTAMP(12)
     if (!scat) return false;
     if (att) { att[0] = atr; att[1] = atg; att[2] = atb; }
     // recur: scattered ray (time inherited), depth-1, atten*attenuation; accum unchanged (emitted of these is 0)
@@ -1150,7 +1169,9 @@ template <typename R, bool EXT = false>
 __device__ inline bool shade_segment(SceneRef sc, Path<R> &P, R t, int orig, SegLog *lg) {
     if (orig < 0) return false; // miss: (color) returns accum, core.clj:40-41
     HitRec<R> h;
+    RTMI_SUBSTAMP(-1)
     resolve_any<R, EXT>(sc, P, t, orig, h, false);
+    RTMI_SUBSTAMP(8)
     const bool scat = scatter_emit<R, EXT>(sc, P, h, nullptr);
     if (lg && lg->n < lg->max_seg) {
         double *q = lg->rec + (size_t)lg->n * RTMI_SEG_REC;
