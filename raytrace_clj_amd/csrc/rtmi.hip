@@ -1272,6 +1272,20 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
                 if (t < 0 || t >= n_tex || uses[(size_t)t]) pk_dev[(size_t)i] |= RTMI_PRIM_NEEDS_UV;
             }
         if (!rc) rc = upload(s, pk_dev, &d.prim_kind);
+        std::vector<int> km((size_t)std::max(n_prims, 1) * 2, 0);
+        for (int i = 0; i < n_prims; ++i) { km[2 * (size_t)i] = pk_dev[(size_t)i]; km[2 * (size_t)i + 1] = pm[(size_t)i]; }
+        if (!rc) rc = upload(s, km, &d.prim_km);
+        std::vector<double> mrec((size_t)std::max(n_mats, 1) * 8, 0.0);
+        for (int m = 0; m < n_mats; ++m) {
+            MatRec r;
+            std::memset(&r, 0, sizeof(r));
+            r.mat_kind = mat_kind[m]; r.tex = mat_tex[m]; r.param = mat_param[m];
+            r.tex_kind = (r.tex >= 0 && r.tex < n_tex) ? tex_kind[r.tex] : -1;
+            if (r.tex_kind == RTMI_TEX_CONSTANT) { const double *tp = tex_param + (size_t)r.tex * RTMI_TEX_STRIDE; r.r = tp[0]; r.g = tp[1]; r.b = tp[2]; }
+            static_assert(sizeof(MatRec) == 64, "MatRec is eight doubles");
+            std::memcpy(&mrec[(size_t)m * 8], &r, sizeof(r));
+        }
+        if (!rc) rc = upload(s, mrec, &d.mat_rec);
     }
     if (!rc) rc = upload(s, pm, &d.prim_mat);
     if (!rc) rc = upload(s, mk, &d.mat_kind);

@@ -57,6 +57,8 @@ struct DevScene {
     const int *mov_orig;
     const int *prim_kind;    // by original index
     const int *prim_mat;
+    const int *prim_km;      // [n][2] = (prim_kind incl. RTMI_PRIM_NEEDS_UV, prim_mat): one 8-byte fetch for the winner
+    const double *mat_rec;   // [n_mats][8]: MatRec -- what scatter needs about a material, in one record (no chain of dependent fetches)
     const int *mat_kind;
     const int *mat_tex;
     const double *mat_param;
@@ -987,6 +989,9 @@ template <typename R> struct HitRec { R t, px, py, pz, nx, ny, nz, u, v; int ori
 // Rebuild the hit record of primitive `orig` (original Hitlist index) at parameter t: centre (hitable.clj:219-222 for moving
 // spheres), p = point-at-parameter (util.clj:18-22), normal = normalise(p - centre) (hitable.clj:194),
 // uv = get-sphere-uv for UVSphere (hitable.clj:128-139) else [0 0].
+// One record per material: kind, its parameter, the root texture and -- for the common constant texture -- the colour itself.
+struct __attribute__((aligned(16))) MatRec { int mat_kind, tex, tex_kind, pad; double param, r, g, b; double pad2[2]; };
+
 // `all_uv`: the probes report uv of every UVSphere hit; the trace kernel computes it (atan2 + asin) only where the hit material's
 // texture reads uv (bit RTMI_PRIM_NEEDS_UV of the device copy of prim_kind: e.g. not for a constant-colour sky dome).
 #define RTMI_PRIM_NEEDS_UV 32
@@ -999,9 +1004,10 @@ template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path
         const R f = (P.time - t0) / (t1 - t0), omf = R(1.0) - f;
         cx = (R)g[0] * omf + (R)g[4] * f; cy = (R)g[1] * omf + (R)g[5] * f; cz = (R)g[2] * omf + (R)g[6] * f;
     }
-    const int kind_flags = sc.prim_kind[h.orig];
+    const int2 km = reinterpret_cast<const int2 *>(sc.prim_km)[h.orig];
+    const int kind_flags = km.x;
     h.kind = kind_flags & 15;
-    h.mat = sc.prim_mat[h.orig];
+    h.mat = km.y;
     h.t = t;
     h.px = P.dx * t + P.ox; h.py = P.dy * t + P.oy; h.pz = P.dz * t + P.oz;
     R nx = h.px - cx, ny = h.py - cy, nz = h.pz - cz;
@@ -1085,7 +1091,10 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
     // wave hold different materials, so every copy would be executed serially.  Per lane the operations and the draw
     // order are exactly those of the material's own scatter.
     const int mat = h.mat;
-    const int mk = sc.mat_kind[mat];
+    const double2 *mq = reinterpret_cast<const double2 *>(sc.mat_rec + (size_t)mat * 8);
+    const double2 m0 = mq[0], m1 = mq[1], m2 = mq[2]; // 48 bytes: header, param + r, g + b
+    const int mk = (int)__double2loint(m0.x), mtex = (int)__double2hiint(m0.x), mtk = (int)__double2loint(m0.y);
+    const R mparam = (R)m1.x;
     const R px = h.px, py = h.py, pz = h.pz, nx = h.nx, ny = h.ny, nz = h.nz;
     const bool is_light = mk == RTMI_MAT_DIFFUSE_LIGHT;
     const bool live = !is_light && P.depth > 0; // core.clj:27: (and (pos? depth) (scatter ...))
@@ -1116,13 +1125,13 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
         P.time = h.t;
         scat = true;
     } else if (is_metal) { // shader.clj:46-57 + reflect shader.clj:6-9
-        const R fuzz = (R)sc.mat_param[mat];
+        const R fuzz = mparam;
         const R k = R(2.0) * dot3(ux, uy, uz, nx, ny, nz);
         const R rfx = ux - k * nx, rfy = uy - k * ny, rfz = uz - k * nz;
         sdx = rfx + fuzz * rx; sdy = rfy + fuzz * ry; sdz = rfz + fuzz * rz;
         scat = dot3(sdx, sdy, sdz, nx, ny, nz) > R(0);
     } else if (is_diel) { // shader.clj:76-102, refract 11-20, schlick 69-74
-        const R ri = (R)sc.mat_param[mat];
+        const R ri = mparam;
         const R dn = dot3(P.dx, P.dy, P.dz, nx, ny, nz);
         R onx, ony, onz, eta, cosine;
         if (dn > R(0)) { onx = -nx; ony = -ny; onz = -nz; eta = ri; cosine = ri * (dn / dmag); }
@@ -1150,7 +1159,8 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
     // Lambertian / Metal scatter (shader.clj:34,57)
     if (is_light || is_lamb || is_iso || (is_metal && scat)) {
         R tr, tg, tb;
-        tex_sample<R, F4>(sc, sc.mat_tex[mat], h.u, h.v, px, py, pz, tr, tg, tb);
+        if (mtk == RTMI_TEX_CONSTANT) { tr = (R)m1.y; tg = (R)m2.x; tb = (R)m2.y; } // texture.clj:14-16, the colour came with the record
+        else tex_sample<R, F4>(sc, mtex, h.u, h.v, px, py, pz, tr, tg, tb);
         if (is_light) { P.cr = P.cr + P.ar * tr; P.cg = P.cg + P.ag * tg; P.cb = P.cb + P.ab * tb; } // core.clj:37-39
         else { atr = tr; atg = tg; atb = tb; }
     }
