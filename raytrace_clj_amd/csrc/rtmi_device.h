@@ -999,12 +999,12 @@ template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path
     const double *g = sc.exact12 + (size_t)orig * 12;
     R cx = (R)g[0], cy = (R)g[1], cz = (R)g[2];
     h.orig = orig;
-    if (g[9] != 0.0) { // MovingSphere: centre at the ray's time (hitable.clj:219-222)
+    const int2 km = reinterpret_cast<const int2 *>(sc.prim_km)[orig];
+    if ((km.x & 15) == RTMI_PRIM_MOVING) { // MovingSphere: centre at the ray's time (hitable.clj:219-222)
         const R t0 = (R)g[7], t1 = (R)g[8];
         const R f = (P.time - t0) / (t1 - t0), omf = R(1.0) - f;
         cx = (R)g[0] * omf + (R)g[4] * f; cy = (R)g[1] * omf + (R)g[5] * f; cz = (R)g[2] * omf + (R)g[6] * f;
     }
-    const int2 km = reinterpret_cast<const int2 *>(sc.prim_km)[h.orig];
     const int kind_flags = km.x;
     h.kind = kind_flags & 15;
     h.mat = km.y;
