@@ -35,6 +35,10 @@ using namespace rtmi;
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef RTMI_TRACE_BLOCK
+#define RTMI_TRACE_BLOCK 256
+#endif
+constexpr int kTraceBlock = RTMI_TRACE_BLOCK; // threads per workgroup of the trace kernel
 // Diagnostic build only (make stamps -> librtmi_stamps.so): s_memtime around the phases of a loop trip, summed per wave and
 // added to g_stamps[phase], printed to stderr after every render.  Never defined in the shipped library.
 #ifdef RTMI_STAMPS
@@ -183,7 +187,7 @@ template <typename R> __device__ inline void start_sample(SceneRef sc, const Tra
 }
 
 template <typename R, bool MULTI, int VARIANT, bool EXT = false>
-__global__ void __launch_bounds__(kBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
+__global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
     SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Prim4<R> *lds = reinterpret_cast<Prim4<R> *>(smem);
@@ -630,7 +634,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         const int variant = c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant;
         void (*kern)(ScenePtr, TraceParams) = nullptr;
         size_t dyn_lds = 0;
-        const size_t bvh_lds = (size_t)RTMI_BVH_STACK * kBlock * sizeof(int);
+        const size_t bvh_lds = (size_t)RTMI_BVH_STACK * kTraceBlock * sizeof(int);
         if (s->dev.has_ext) { // section 8(f3) scenes: FP64 kernels with the mixed-kind intersectors
             if (variant == SCAN_BVH) { kern = trace_kernel<double, false, SCAN_BVH, true>; dyn_lds = bvh_lds; }
             else kern = trace_kernel<double, false, SCAN_SGPR_CULL, true>;
@@ -644,10 +648,10 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         }
         // persistent launch: as many workgroups as stay resident (at most blocks_per_cu per CU); the queue feeds them
         int resident = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, kBlock, dyn_lds));
-        const int grid_trace = std::max(1, c->cus * std::max(1, std::min(c->blocks_per_cu, resident)));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, kTraceBlock, dyn_lds));
+        const int grid_trace = std::max(1, c->cus * std::max(1, std::min(c->blocks_per_cu * (256 / kTraceBlock), resident)));
         c->last_grid = grid_trace;
-        hipLaunchKernelGGL(kern, dim3(grid_trace), dim3(kBlock), dyn_lds, st, s->d_dev, tp);
+        hipLaunchKernelGGL(kern, dim3(grid_trace), dim3(kTraceBlock), dyn_lds, st, s->d_dev, tp);
         HIP_TRY(hipGetLastError());
         if (e1) HIP_TRY(hipEventRecord(e1, st));
         const long long npx = (long long)n_local * 64;
