@@ -441,7 +441,7 @@ def test_bench_json_schema():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"], k
     assert d["other_accel"]["accel"] == "flat" and d["other_accel"]["value"] > 100
-    assert d["config"]["frames_in_flight"] == 2 and d["serial"]["value"] > 100 and d["roofline"]["pipelined_launch_ms"] >= d["roofline"]["launch_ms"] > 0
+    assert d["config"]["frames_in_flight"] == 2 and d["serial"]["value"] > 100 and d["roofline"]["pipelined_launch_ms"] > 0 and d["roofline"]["launch_ms"] > 0
 
 
 def test_frame_pipeline_renders_the_same_frames():
@@ -756,9 +756,10 @@ def test_render_matches_golden(name):
     assert (q != z["rgb8"]).mean() < 1e-3 and np.abs(q.astype(int) - z["rgb8"].astype(int)).max() <= 1
 
 
-@pytest.mark.parametrize("cfg", [(200, 100, 4, 11, False), (96, 56, 8, 11, True), (61, 37, 5, 3, False)])
+@pytest.mark.parametrize("cfg", [(200, 100, 4, 11, False), (96, 56, 8, 11, True), (61, 37, 5, 3, False), (20, 13, 1, 3, True), (1, 1, 3, 3, False)])
 def test_render_matches_oracle(oracle, cfg):
-    nx, ny, ns, n, moving = cfg  # (200,100,4) is BASELINE config 0; 61x37 exercises partial 8x8 tiles
+    # (200,100,4) is BASELINE config 0; 61x37 exercises partial 8x8 tiles; 20x13x1 = 6 chunks = 1.5 work-queue claims; 1x1: one pixel
+    nx, ny, ns, n, moving = cfg
     sc = r.scene.make_random_scene(nx, ny, n, moving)
     f = fl.flatten(sc)
     exp_lin, exp_q, exp_cnt = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, nthreads=16)
