@@ -1279,15 +1279,24 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
         std::vector<int> km((size_t)std::max(n_prims, 1) * 2, 0);
         for (int i = 0; i < n_prims; ++i) { km[2 * (size_t)i] = pk_dev[(size_t)i]; km[2 * (size_t)i + 1] = pm[(size_t)i]; }
         if (!rc) rc = upload(s, km, &d.prim_km);
-        std::vector<double> mrec((size_t)std::max(n_mats, 1) * 8, 0.0);
+        std::vector<double> mrec((size_t)std::max(n_mats, 1) * 12, 0.0);
         for (int m = 0; m < n_mats; ++m) {
             MatRec r;
             std::memset(&r, 0, sizeof(r));
             r.mat_kind = mat_kind[m]; r.tex = mat_tex[m]; r.param = mat_param[m];
             r.tex_kind = (r.tex >= 0 && r.tex < n_tex) ? tex_kind[r.tex] : -1;
             if (r.tex_kind == RTMI_TEX_CONSTANT) { const double *tp = tex_param + (size_t)r.tex * RTMI_TEX_STRIDE; r.r = tp[0]; r.g = tp[1]; r.b = tp[2]; }
-            static_assert(sizeof(MatRec) == 64, "MatRec is eight doubles");
-            std::memcpy(&mrec[(size_t)m * 8], &r, sizeof(r));
+            if (r.tex_kind == RTMI_TEX_CHECKER) { // both children Constant: the whole texture fits the record
+                const int c0 = tex_child[2 * (size_t)r.tex], c1 = tex_child[2 * (size_t)r.tex + 1];
+                if (c0 >= 0 && c0 < n_tex && c1 >= 0 && c1 < n_tex && tex_kind[c0] == RTMI_TEX_CONSTANT && tex_kind[c1] == RTMI_TEX_CONSTANT) {
+                    const double *t0 = tex_param + (size_t)c0 * RTMI_TEX_STRIDE, *t1 = tex_param + (size_t)c1 * RTMI_TEX_STRIDE;
+                    r.tex_kind = RTMI_TEX_CHECKER2;
+                    r.scale = tex_param[(size_t)r.tex * RTMI_TEX_STRIDE];
+                    r.r = t0[0]; r.g = t0[1]; r.b = t0[2]; r.c1r = t1[0]; r.c1g = t1[1]; r.c1b = t1[2];
+                }
+            }
+            static_assert(sizeof(MatRec) == 96, "MatRec is twelve doubles");
+            std::memcpy(&mrec[(size_t)m * 12], &r, sizeof(r));
         }
         if (!rc) rc = upload(s, mrec, &d.mat_rec);
     }

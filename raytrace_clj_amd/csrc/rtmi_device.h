@@ -58,7 +58,7 @@ struct DevScene {
     const int *prim_kind;    // by original index
     const int *prim_mat;
     const int *prim_km;      // [n][2] = (prim_kind incl. RTMI_PRIM_NEEDS_UV, prim_mat): one 8-byte fetch for the winner
-    const double *mat_rec;   // [n_mats][8]: MatRec -- what scatter needs about a material, in one record (no chain of dependent fetches)
+    const double *mat_rec;   // [n_mats][12]: MatRec -- what scatter needs about a material, in one record (no chain of dependent fetches)
     const int *mat_kind;
     const int *mat_tex;
     const double *mat_param;
@@ -990,7 +990,10 @@ template <typename R> struct HitRec { R t, px, py, pz, nx, ny, nz, u, v; int ori
 // spheres), p = point-at-parameter (util.clj:18-22), normal = normalise(p - centre) (hitable.clj:194),
 // uv = get-sphere-uv for UVSphere (hitable.clj:128-139) else [0 0].
 // One record per material: kind, its parameter, the root texture and -- for the common constant texture -- the colour itself.
-struct __attribute__((aligned(16))) MatRec { int mat_kind, tex, tex_kind, pad; double param, r, g, b; double pad2[2]; };
+// tex_kind = RTMI_TEX_CHECKER2 (record-only code): a Checkerboard of two Constant textures -- the two colours and the scale are in
+// the record as well (r,g,b = tex0 = the colour where the sine product is negative; c1 = tex1), texture.clj:44-50.
+#define RTMI_TEX_CHECKER2 100
+struct __attribute__((aligned(16))) MatRec { int mat_kind, tex, tex_kind, pad; double param, r, g, b; double scale, c1r, c1g, c1b; double pad2[2]; };
 
 // `all_uv`: the probes report uv of every UVSphere hit; the trace kernel computes it (atan2 + asin) only where the hit material's
 // texture reads uv (bit RTMI_PRIM_NEEDS_UV of the device copy of prim_kind: e.g. not for a constant-colour sky dome).
@@ -1091,7 +1094,7 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
     // wave hold different materials, so every copy would be executed serially.  Per lane the operations and the draw
     // order are exactly those of the material's own scatter.
     const int mat = h.mat;
-    const double2 *mq = reinterpret_cast<const double2 *>(sc.mat_rec + (size_t)mat * 8);
+    const double2 *mq = reinterpret_cast<const double2 *>(sc.mat_rec + (size_t)mat * 12);
     const double2 m0 = mq[0], m1 = mq[1], m2 = mq[2]; // 48 bytes: header, param + r, g + b
     const int mk = (int)__double2loint(m0.x), mtex = (int)__double2hiint(m0.x), mtk = (int)__double2loint(m0.y);
     const R mparam = (R)m1.x;
@@ -1160,7 +1163,13 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
     if (is_light || is_lamb || is_iso || (is_metal && scat)) {
         R tr, tg, tb;
         if (mtk == RTMI_TEX_CONSTANT) { tr = (R)m1.y; tg = (R)m2.x; tb = (R)m2.y; } // texture.clj:14-16, the colour came with the record
-        else tex_sample<R, F4>(sc, mtex, h.u, h.v, px, py, pz, tr, tg, tb);
+        else if (mtk == RTMI_TEX_CHECKER2) { // texture.clj:44-50 with both children Constant
+            const double2 m3 = mq[3], m4 = mq[4];
+            const R scale = (R)m3.x;
+            const int sx = sin_sign<R>(scale * px), sy = sin_sign<R>(scale * py), sz = sin_sign<R>(scale * pz);
+            const bool neg = sx * sy * sz < 0;
+            tr = neg ? (R)m1.y : (R)m3.y; tg = neg ? (R)m2.x : (R)m4.x; tb = neg ? (R)m2.y : (R)m4.y;
+        } else tex_sample<R, F4>(sc, mtex, h.u, h.v, px, py, pz, tr, tg, tb);
         if (is_light) { P.cr = P.cr + P.ar * tr; P.cg = P.cg + P.ag * tg; P.cb = P.cb + P.ab * tb; } // core.clj:37-39
         else { atr = tr; atg = tg; atb = tb; }
     }
