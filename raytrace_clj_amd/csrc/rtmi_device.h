@@ -125,7 +125,7 @@ template <> struct Real<float> {
     __device__ static inline float pow_(float x, float y) { return ::powf(x, y); }
 };
 
-// x^5 for Schlick's approximation (shader.clj:69-74: (Math/pow (- 1.0 cosine) 5.0)).  Math/pow and the oracle's libm pow are
+// x^5 for Schlick's approximation (shader.clj:69-74: (Math/pow (- 1.0 cosine) 5.0)).  Math/pow and a host libm pow are
 // (almost always) correctly rounded; a generic device pow() is ~200 FP64 instructions and no closer.  Three double-double
 // products keep the error below 2^-100 before the final rounding, i.e. the correctly rounded power except for near-ties.
 __device__ inline double pow5(double x) {
