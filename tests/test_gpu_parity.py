@@ -444,6 +444,23 @@ def test_bench_json_schema():
     assert d["config"]["frames_in_flight"] == 2 and d["serial"]["value"] > 100 and d["roofline"]["pipelined_launch_ms"] > 0 and d["roofline"]["launch_ms"] > 0
 
 
+def test_two_rank_control_flow_rehearsal():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), except that both ranks share this
+    box's one GPU and the gather goes through gloo on the host (RTMI_BENCH_REHEARSAL=1): tile dealing, per-rank renders, gather,
+    assemble, max-over-ranks timing and the JSON line of the N > 1 path"""
+    import subprocess, sys
+    env = dict(os.environ, RTMI_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "C1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["ns"] == 8 and d["value"] > 0 and "cpu_baseline" not in d
+    assert abs(d["config"]["segments_per_sample"] - 2.5) < 0.6  # both ranks' segment counters were summed
+
+
 def test_frame_pipeline_renders_the_same_frames():
     """two render slots on two streams (dist.FramePipeline): every frame equals the one-slot render, counters included"""
     import torch
