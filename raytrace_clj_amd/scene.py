@@ -63,6 +63,17 @@ def make_two_perlin_spheres(nx, ny, seed=SCENE_SEED):
     }
 
 
+def _earth(image):
+    """the reference reads "earth.png" from the working directory (scene.clj:125, 426); the file is not in its repository, so: the
+    caller's pixels, else ./earth.png when there is one (PNG decoder in texture.py), else the synthetic stand-in"""
+    import os
+    if image is not None:
+        return tex.image_map(image=image)
+    if os.path.exists("earth.png"):
+        return tex.image_map(filename="earth.png")
+    return tex.image_map(image=synthetic_earth())
+
+
 def synthetic_earth(w=256, h=128):
     """stand-in for the reference's earth.png (scene.clj:125-126: not in the repository, *.png is git-ignored): a
     deterministic land/ocean pattern, [h, w, 3] uint8"""
@@ -80,7 +91,7 @@ def make_textured_sphere(nx, ny, image=None, seed=SCENE_SEED):
     """texture mapped sphere -- scene.clj:116-150 (earth.png replaced by `image`, default synthetic_earth())"""
     rng = SplitMix64(seed)
     checker = tex.checkerboard(tex0=tex.constant(color=vec3(0.2, 0.3, 0.1)), tex1=tex.constant(color=vec3(0.9, 0.9, 0.9)), scale=10)
-    earth = tex.flip_texture_v(tex=tex.image_map(image=synthetic_earth() if image is None else image))
+    earth = tex.flip_texture_v(tex=_earth(image))
     return {
         "camera": cam.thin_lens_camera(lookfrom=vec3(13, 2, 3), lookat=vec3(0, 1, 0), vup=vec3(0, 1, 0), vfov=15,
                                        aspect=_aspect(nx, ny), aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0),
@@ -183,7 +194,7 @@ def make_final(nx, ny, image=None, seed=SCENE_SEED):
     glass = shad.dielectric(ri=1.5)
     metal = shad.metal(albedo=tex.constant(color=vec3(0.8, 0.8, 0.9)), fuzz=10)
     bndry = hit.sphere(center=vec3(360, 150, 145), radius=70, material=glass)
-    earth = shad.lambertian(albedo=tex.flip_texture_v(tex=tex.image_map(image=synthetic_earth() if image is None else image)))
+    earth = shad.lambertian(albedo=tex.flip_texture_v(tex=_earth(image)))
     marble = shad.lambertian(albedo=tex.marble(scale=0.1, depth=4))
     nb, ns = 20, 1000
     boxes = []

@@ -237,3 +237,51 @@ def test_png_and_ppm_writers_round_trip(tmp_path):
     core.save_ppm(tmp_path / "a.ppm", img)
     data = (tmp_path / "a.ppm").read_bytes()
     assert data.startswith(b"P6\n53 37\n255\n") and np.array_equal(np.frombuffer(data[len(b"P6\n53 37\n255\n"):], np.uint8).reshape(37, 53, 3), img)
+
+
+def test_image_map_reads_png(tmp_path):
+    """(image-map :filename "earth.png") -- texture.clj:135-138: the PNG decoder against the writer of this package and against a
+    hand-filtered file (every scanline filter type, RGBA and palette colour types)"""
+    import struct
+    import zlib
+    from raytrace_clj_amd import core, texture
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (11, 7, 3), dtype=np.uint8)
+    core.save_png(tmp_path / "t.png", img)
+    assert np.array_equal(texture.image_map(filename=str(tmp_path / "t.png")).image, img)
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    def encode(px, ctype, filters, palette=None):  # px [h, w, ch]; apply the given filter type per row
+        h, w, ch = px.shape
+        rows, prev = [], np.zeros(w * ch, np.int32)
+        for y in range(h):
+            cur = px[y].reshape(-1).astype(np.int32)
+            ft = filters[y % len(filters)]
+            a = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+            c = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+            if ft == 0: pred = 0
+            elif ft == 1: pred = a
+            elif ft == 2: pred = prev
+            elif ft == 3: pred = (a + prev) >> 1
+            else:
+                p0 = a + prev - c
+                pa, pb, pc = abs(p0 - a), abs(p0 - prev), abs(p0 - c)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+            rows.append(bytes([ft]) + ((cur - pred) & 255).astype(np.uint8).tobytes())
+            prev = cur
+        body = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+        if palette is not None:
+            body += chunk(b"PLTE", palette.tobytes())
+        return body + chunk(b"IDAT", zlib.compress(b"".join(rows))) + chunk(b"IEND", b"")
+
+    rgba = rng.integers(0, 256, (9, 6, 4), dtype=np.uint8)
+    assert np.array_equal(texture.decode_png(encode(rgba, 6, [0, 1, 2, 3, 4])), rgba[:, :, :3])
+    pal = rng.integers(0, 256, (5, 3), dtype=np.uint8)
+    idx = rng.integers(0, 5, (8, 10, 1), dtype=np.uint8)
+    assert np.array_equal(texture.decode_png(encode(idx, 3, [4, 3, 1], palette=pal)), pal[idx[:, :, 0]])
+    grey = rng.integers(0, 256, (4, 5, 1), dtype=np.uint8)
+    assert np.array_equal(texture.decode_png(encode(grey, 0, [2, 4])), np.repeat(grey, 3, axis=2))
+    with pytest.raises(ValueError):
+        texture.decode_png(b"not a png")
