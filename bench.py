@@ -3,15 +3,25 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one frame of synthetic input (the seeded Shirley cover scene): every
-rank renders its round-robin 8x8 tiles of the frame from the HBM-resident scene, one gather brings the tiles to rank 0,
-rank 0 assembles + quantises.  At N=1 the workload is BASELINE configs[1] (800x400x64spp, cover scene n=11, depth 50);
-at N>1 the per-GPU work is kept fixed (weak scaling): the same frame at 64*N spp.  Inputs and outputs stay in HBM.
-Consecutive steps (frames) alternate between two render slots on two HIP streams (--frames-in-flight, default 2), so a
-frame's first workgroups fill the CUs that the previous frame's last, deep paths leave idle; the JSON also carries the
-one-frame-in-flight figure ("serial").
-One JSON line is printed by rank 0; see DESIGN.md for the roofline arithmetic."""
+A "step" is one pass of the hot path over one frame of synthetic input (the seeded Shirley cover scene): every GPU renders
+its round-robin 8x8 tiles of the frame from the HBM-resident scene, one gather brings the tiles to GPU 0, GPU 0 assembles +
+quantises.  Inputs and outputs stay in HBM.
+
+  N = 1  BASELINE configs[2], the configuration the north star's target is quoted on: C3 = 1920x1080x256spp, cover scene
+         n=50 (10 003 spheres), depth 50, BVH.  One frame in flight; `value` = samples / wall time of the K steps.  Extra keys
+         (outside the timed region): "pipelined" (two frames in flight), "c2" (configs[1]), "c4" (configs[3] on one GPU, the
+         N = 1 point of the strong-scaling curve), "cpu_baseline".
+  N > 1  BASELINE configs[3]: C4 = 3840x2160x512spp cover scene n=11, STRONG scaling (the frame is fixed, its tiles are dealt
+         round-robin over the N GPUs), the gather reported separately ("gather_ms").  Two launch forms, same arithmetic:
+           * `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the driver's form): one process per GPU,
+             tiles gathered by torch.distributed (RCCL);
+           * `python bench.py --gpus N` (one host process, as the reference's one JVM): rtmi_render_multi_device, the gather is
+             ONE ncclGather inside librtmi.so.  With fewer than N visible devices the replicas share devices and the JSON says
+             "rehearsal": true (control flow only, never a measurement).
+
+One JSON line is printed by rank 0; DESIGN.md section 6 explains the roofline object."""
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,33 +44,127 @@ CONFIGS = {
     # ConstantMedium volumes, marble / image textures, a moving sphere, a rectangle light
     "FINAL": (500, 500, 128, 0, False, None),
 }
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
-FP64_PEAK_TFLOPS = 78.6     # vector FP64 (spec)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; VALU issue peak = 1024 x 2.4e9 SIMD-cycles / s
+FP64_PEAK_TFLOPS = 78.6
 FP32_PEAK_TFLOPS = 157.3
 
 
-def cpu_baseline(flat, nx, ny, ns, budget_s=15.0):
+def kernel_sha():
+    """identifies the kernel sources a PMC profile was taken with"""
+    h = hashlib.sha256()
+    for f in ("rtmi.hip", "rtmi_device.h"):
+        h.update(open(os.path.join(ROOT, "raytrace_clj_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def build_scene(r, name):
+    nx, ny, ns, n, moving, mix = CONFIGS[name]
+    if name == "CB":
+        scene = r.scene.make_cornell_box(nx, ny)
+    elif name == "FINAL":
+        scene = r.scene.make_final(nx, ny)
+    else:
+        scene = r.scene.make_random_scene(nx, ny, n, moving, mix=mix)
+    return scene, r.flatten.flatten(scene)
+
+
+def workload_text(name, nx, ny, ns, n_prims, accel, world):
+    n, moving = CONFIGS[name][3], CONFIGS[name][4]
+    if name == "CB":
+        return "%s: %dx%dx%dspp classic Cornell box (%d rectangles via Translate/RotateY/FlipNormals), depth 50; accel=%s; %d GPU(s)" % (name, nx, ny, ns, n_prims, accel, world)
+    if name == "FINAL":
+        return "%s: %dx%dx%dspp make-final (scene.clj:415-489; %d primitives), depth 50; accel=%s; %d GPU(s)" % (name, nx, ny, ns, n_prims, accel, world)
+    return ("%s: %dx%dx%dspp Shirley cover scene n=%d (%d spheres%s), depth 50, thin-lens camera, seeded counter RNG; accel=%s; "
+            "8x8 tiles dealt round-robin to %d GPU(s)" % (name, nx, ny, ns, n, n_prims, ", moving" if moving else "", accel, world))
+
+
+def cpu_baseline(scene, flat, nx, ny, ns, budget_s=15.0):
     """The CPU oracle (oracle/rt_oracle.c, a restatement of the reference path -- NOT the JVM) timed on this box's host
-    cores (32-pixel chunks over a thread pool, like core.clj:100-108) on a bounded sample of the same workload: every
-    k-th row of the frame at full spp, k chosen so the sample takes about budget_s seconds."""
+    cores (32-pixel chunks over a thread pool, like core.clj:100-108) on a bounded sample of the same workload: evenly
+    spaced rows of the frame at full spp, as many as fit in about budget_s seconds.  It walks the world as the reference
+    builds it (nested bvh-node records, both children visited: hitable.clj:97-123)."""
+    import copy
     from oracle.oracle import Oracle
+    from oracle.tree import attach_tree
+    fl = copy.copy(flat)
+    attach_tree(fl, scene["world"])
     orc = Oracle("f64")
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = min(cores, 256)
     t0 = time.time()
-    orc.render(flat, nx, ny, ns, 50, 0x5EED0002, region=(0, ny // 2, nx, ny // 2 + 1), nthreads=threads)
+    orc.render(fl, nx, ny, ns, 50, 0x5EED0002, region=(0, ny // 2, nx, ny // 2 + 1), nthreads=threads)
     per_row = max(time.time() - t0, 1e-3)
     n_rows = int(max(1, min(ny, budget_s / per_row)))
     rows = [int(round(i * (ny - 1) / max(1, n_rows - 1))) for i in range(n_rows)] if n_rows > 1 else [ny // 2]
     rows = sorted(set(rows))
     samples, t0 = 0, time.time()
     for y in rows:
-        orc.render(flat, nx, ny, ns, 50, 0x5EED0002, region=(0, y, nx, y + 1), nthreads=threads)
+        orc.render(fl, nx, ny, ns, 50, 0x5EED0002, region=(0, y, nx, y + 1), nthreads=threads)
         samples += nx * ns
     dt = time.time() - t0
     return {"value": round(samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": "%d evenly spaced rows of the %dx%d frame at %d spp (%d samples, %.1f s); C restatement of the reference path, not the JVM"
-                      % (len(rows), nx, ny, ns, samples, dt)}
+            "sample": "%d evenly spaced rows of the %dx%d frame at %d spp (%d samples, %.1f s); C restatement of the reference path "
+                      "walking the reference's own bvh-node tree, not the JVM" % (len(rows), nx, ny, ns, samples, dt)}
+
+
+def roofline(cfg, accel, precision, n_prims, launch_s, launches_per_step, counts, share=1.0):
+    """The dominant kernel (trace_kernel) priced per launch.  counts: per FRAME on this GPU {segments, samples, pixels,
+    aabb_tests, prim_tests} from the device counters (live, counting instantiation run outside the timed region).
+    share: fraction of the profiled whole-frame instruction counts this GPU executes (1/N under the tile partition)."""
+    per = 1.0 / max(1, launches_per_step)
+    S, smp, pix = counts["segments"] * per, counts["samples"] * per, counts["pixels"]
+    rec = 32 if precision == "f64" else 16
+    out = {"kernel": "trace_kernel<%s,%s>" % (precision, "BVH" if accel == "bvh" else "flat scan + FP32 cull"),
+           "launch_ms": round(launch_s * 1e3, 4), "launches_per_step": launches_per_step}
+    if accel == "bvh":
+        visits, leaves = counts["aabb_tests"] * per / 2.0, counts["prim_tests"] * per
+        bytes_alg = visits * 32.0 + leaves * 32.0 + S * 96.0 + smp * 24.0 + pix * 12.0
+        model = ("algorithmic bytes = inner-node visits x 32 (one half-plane node record) + exact primitive tests x 32 (cx cy cz r^2) + "
+                 "segments x 96 (material record) + samples x 24 (per-sample colour) + pixels x 12")
+    else:
+        bytes_alg = S * n_prims * rec / 256.0 + pix * 12.0
+        model = "algorithmic bytes = S*N*REC/256 + 12*pixels (SURVEY.md 8d: the Hitlist scan with a 256-ray LDS tile)"
+        out["flat_scan_flops"] = {"achieved": round(S * (n_prims * 20.0 + 120.0) / launch_s / 1e12, 3), "unit": "TFLOP/s",
+                                  "peak": FP64_PEAK_TFLOPS if precision == "f64" else FP32_PEAK_TFLOPS,
+                                  "note": "reference-equivalent flops S*(20N+120) of SURVEY.md 8d; the FP32 cull skips most FP64 work, so this "
+                                          "is work avoided, not ALU utilisation"}
+    hbm_gbs = bytes_alg / launch_s / 1e9
+    out["hbm"] = {"achieved": round(hbm_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 5),
+                  "algorithmic_bytes_per_launch": round(bytes_alg), "model": model, "target_40pct_met": False,
+                  "note": "the north star's >= 40 % of the HBM-read roofline is NOT met and cannot be by this design: the scene (<= 1 MB) "
+                          "stays on chip (scalar cache / L1 / L2), so the kernel's HBM traffic is the per-sample colours it writes, not "
+                          "scene reads (SURVEY.md 8d says the same of any on-chip-reuse design)"}
+    prof = None
+    try:
+        allp = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json")))
+        prof = allp.get("%s/%s/%s" % (cfg, accel, precision))
+    except (OSError, ValueError):
+        pass
+    if prof:
+        sha = kernel_sha()
+        fp64 = prof["valu_fp64"] * share
+        other = (prof["valu_total"] - prof["valu_fp64"]) * share
+        issue_cycles = fp64 * 4.0 + other * 2.0   # a wave64 instruction occupies its SIMD-32 for 2 cycles, an FP64 one for 4
+        ach = issue_cycles / launch_s / 1e9
+        peak = SIMDS * CLOCK_GHZ
+        traffic = int((prof["fetch_kb"] + prof["write_kb"]) * 1024 * share)
+        out.update({"bound": "valu", "achieved": round(ach, 1), "peak": peak, "unit": "G SIMD issue-cycles/s", "frac": round(ach / peak, 4),
+                    "traffic": traffic,
+                    "lanes_active": prof.get("lanes_active"),
+                    "counts": {"valu_instructions_per_launch": round(prof["valu_total"] * share), "fp64_instructions_per_launch": round(fp64),
+                               "fetch_kb": prof["fetch_kb"], "write_kb": prof["write_kb"], "source": prof.get("source"),
+                               "kernel_sha": prof.get("kernel_sha"), "stale": prof.get("kernel_sha") != sha,
+                               "note": "rocprofv3 PMC counters of this workload's trace_kernel launch (deterministic per launch), imported from "
+                                       "profiles/pmc_counters.json; launch_ms is measured live (HIP events on the launch stream)"},
+                    "note": "binding resource = VALU issue under per-lane traversal divergence: frac = (FP64 instr x 4 + other VALU instr x 2 "
+                            "cycles) / (1024 SIMDs x 2.4 GHz x launch time); lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)"})
+        out["hbm"]["measured_traffic_gbs"] = round(traffic / launch_s / 1e9, 2)
+        out["hbm"]["measured_traffic_frac"] = round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 5)
+    else:
+        out.update({"bound": "valu", "achieved": None, "peak": SIMDS * CLOCK_GHZ, "unit": "G SIMD issue-cycles/s", "frac": None, "traffic": None,
+                    "note": "no PMC profile of this workload under profiles/pmc_counters.json: only the algorithmic HBM figure is priced"})
+    return out
 
 
 def main():
@@ -68,15 +172,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: C3 at --gpus 1, C4 at --gpus N > 1")
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the pipelined / C2 / C4 / other-accel extra measurements")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--accel", default="bvh", choices=["flat", "bvh"], help="bvh = bvh-node descent (hitable.clj:97-123, what every reference scene builds); flat = Hitlist scan (hitable.clj:15-26)")
-    ap.add_argument("--single", action="store_true", help="do not also time the other acceleration structure")
+    ap.add_argument("--single", action="store_true", help="same as --no-extras")
     ap.add_argument("--scan-variant", type=int, default=-1, help="0 LDS literal, 1 LDS pipelined, 2 SGPR (default: library default)")
-    ap.add_argument("--frames-in-flight", type=int, default=2, help="render slots (context + stream) that consecutive steps alternate between")
+    ap.add_argument("--frames-in-flight", type=int, default=1, help="render slots (context + stream) that consecutive steps alternate between (N = 1)")
     args = ap.parse_args()
+    extras = not (args.no_extras or args.single)
 
     import torch
     import torch.distributed as dist
@@ -84,20 +190,24 @@ def main():
     import raytrace_clj_amd as r
     from raytrace_clj_amd import dist as rdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if env_world > 1 and args.gpus != env_world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, env_world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
-    # RTMI_BENCH_REHEARSAL=1: several ranks share GPU 0 and the gather goes through gloo on the host -- only to rehearse the
-    # multi-rank control flow on a one-GPU box; never a measurement
-    rehearsal = os.environ.get("RTMI_BENCH_REHEARSAL") == "1"
-    if rehearsal:
+    multi_proc = env_world > 1                      # one process per GPU (torch.distributed.run)
+    in_library = args.gpus > 1 and not multi_proc   # one host process, rtmi_render_multi_device
+    world = args.gpus
+    visible = torch.cuda.device_count()
+    # RTMI_BENCH_REHEARSAL=1 (multi-process form): the ranks share GPU 0 and the gather goes through gloo on the host -- only to
+    # rehearse the multi-rank control flow on a one-GPU box; never a measurement
+    rehearsal = (multi_proc and os.environ.get("RTMI_BENCH_REHEARSAL") == "1") or (in_library and visible < world)
+    if multi_proc and rehearsal:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
+    torch.cuda.set_device(local_rank if multi_proc else 0)
+    if multi_proc:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -105,134 +215,178 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    nx, ny, ns1, n, moving, mix = CONFIGS[args.config]
-    ns = ns1 * world  # weak scaling: per-GPU work fixed
-    if args.config == "CB":
-        scene = r.scene.make_cornell_box(nx, ny)
-    elif args.config == "FINAL":
-        scene = r.scene.make_final(nx, ny)
-    else:
-        scene = r.scene.make_random_scene(nx, ny, n, moving, mix=mix)
-    flat = r.flatten.flatten(scene)
-    if args.config in ("CB", "FINAL"):  # the CPU baseline evaluates the nested records like the reference does
-        from oracle.tree import attach_tree
-        attach_tree(flat, scene["world"])
+    cfg = args.config or ("C3" if world == 1 else "C4")
+    nx, ny, ns = CONFIGS[cfg][:3]
+    scene, flat = build_scene(r, cfg)
     options = {}
     if args.blocks_per_cu:
         options["blocks_per_cu"] = args.blocks_per_cu
     if args.scan_variant >= 0:
         options["scan_variant"] = args.scan_variant
-    in_flight = max(1, args.frames_in_flight)
-    pipe = rdist.FramePipeline(flat, nx, ny, rank, world, local_rank, depth=in_flight, timing=True, options=options)
-    pipe1 = pipe if in_flight == 1 else rdist.FramePipeline(flat, nx, ny, rank, world, local_rank, depth=1, timing=True, options=options)
     n_prims = flat.n_prims
-    rec = 32 if args.precision == "f64" else 16
-    peak_t = FP64_PEAK_TFLOPS if args.precision == "f64" else FP32_PEAK_TFLOPS
 
     def barrier():
+        for d in range(visible if in_library else 0):
+            torch.cuda.synchronize(d)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi_proc:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(accel, steps, warmup, pl):
-        """time `steps` steps of the path with the given acceleration structure on pipeline `pl`; returns the result fields"""
-        pl.set_option("accel", 1 if accel == "bvh" else 0)
-        tr = pl.slots[0][2]
-        for _ in range(max(warmup, len(pl.slots))):  # every slot allocates its sample workspace on its first frame: never in the timed region
-            pl.step(ns, precision=args.precision)
+    # ---- the step, in the three launch forms ---------------------------------------------------------------------------
+    class OneGpu:  # N = 1 and the per-rank driver of the multi-process form
+        def __init__(self, flat, nx, ny, in_flight):
+            self.pl = rdist.FramePipeline(flat, nx, ny, rank if multi_proc else 0, world if multi_proc else 1, local_rank if multi_proc else 0,
+                                          depth=in_flight, timing=True, options=options)
+            self.tr = self.pl.slots[0][2]
+            self.slots = len(self.pl.slots)
+
+        def set_option(self, k, v):
+            self.pl.set_option(k, v)
+
+        def step(self, ns):
+            self.pl.step(ns, precision=args.precision)
+
+        def trace_ms(self):
+            return self.pl.last_trace_ms()
+
+        def counters(self):
+            return int(self.tr.counters[0].item()), int(self.tr.counters[1].item())
+
+        def traversal(self):
+            return self.pl.slots[0][0].last_traversal_counters()
+
+        def gather_ms(self):
+            return self.tr.last_gather_ms() if multi_proc else None
+
+    class InLibrary:  # one host process, N devices behind the C-ABI
+        def __init__(self, flat, nx, ny):
+            devs = [i % visible for i in range(world)]
+            self.md = rdist.MultiDevice(flat, devs, timing=True, options=options)
+            d0 = torch.device("cuda", devs[0])
+            self.lin = torch.zeros((ny, nx, 3), dtype=torch.float64, device=d0)
+            self.q = torch.zeros((ny, nx, 3), dtype=torch.uint8, device=d0)
+            self.cnt = torch.zeros(2, dtype=torch.int64, device=d0)
+            self.nx, self.ny, self.slots = nx, ny, 1
+            torch.cuda.synchronize(d0)
+
+        def set_option(self, k, v):
+            self.md.set_option(k, v)
+
+        def step(self, ns):
+            self.md.render_device(self.nx, self.ny, ns, self.lin, self.q, self.cnt, precision=args.precision)
+
+        def trace_ms(self):
+            per = self.md.last_trace_ms()
+            return per[0]  # replica 0's launches (the roofline prices one GPU's kernel)
+
+        def counters(self):
+            self.md.sync()
+            return int(self.cnt[0].item()), int(self.cnt[1].item())
+
+        def traversal(self):
+            a = [c.last_traversal_counters() for c in self.md.ctxs]
+            return sum(x[0] for x in a), sum(x[1] for x in a)
+
+        def gather_ms(self):
+            return self.md.last_gather_ms()
+
+    def measure(drv, accel, steps, warmup, cfg_name, nx, ny, ns, n_prims, count=True):
+        drv.set_option("accel", 1 if accel == "bvh" else 0)
+        drv.set_option("count_traversal", 0)
+        for _ in range(max(warmup, drv.slots)):  # every slot allocates its sample workspace on its first frame: never in the timed region
+            drv.step(ns)
         barrier()
-        pl.last_trace_ms()  # reset the event window
+        drv.trace_ms()  # reset the event window
         t0 = time.perf_counter()
         for _ in range(steps):
-            pl.step(ns, precision=args.precision)
+            drv.step(ns)
         barrier()
         dt = time.perf_counter() - t0
-        trace_ms, launches = pl.last_trace_ms()
-        if world > 1:
+        trace_ms, launches = drv.trace_ms()
+        gather_ms = drv.gather_ms() if world > 1 else None
+        seg_local, pix_local = drv.counters()
+        segments = seg_local
+        if multi_proc:
             coll_dev = "cpu" if rehearsal else "cuda"
             t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-            seg = tr.counters[:1].clone().to(coll_dev)
+            seg = torch.tensor([seg_local], dtype=torch.int64, device=coll_dev)
             dist.all_reduce(seg, op=dist.ReduceOp.SUM)
             segments = int(seg.item())
-        else:
-            segments = int(tr.counters[0].item())
         samples = nx * ny * ns
-        # roofline of the dominant kernel (trace_kernel) on this rank: SURVEY.md 8(d) algorithmic figures per launch
-        seg_local, pix_local = int(tr.counters[0].item()), int(tr.counters[1].item())
+        counts = {"segments": seg_local if multi_proc else segments / (world if in_library else 1), "samples": samples / world, "pixels": nx * ny / world,
+                  "aabb_tests": 0, "prim_tests": 0}
+        if count and accel == "bvh":  # one more frame with the counting instantiation (outside the timed region): node visits / leaf tests
+            drv.set_option("count_traversal", 1)
+            drv.step(ns)
+            barrier()
+            a, b = drv.traversal()
+            drv.set_option("count_traversal", 0)
+            drv.trace_ms()
+            counts["aabb_tests"], counts["prim_tests"] = (a / world, b / world) if in_library else (a, b)
         launches_per_step = max(1, launches // max(1, steps))
         launch_s = trace_ms / 1e3 / max(1, launches)
-        bytes_alg = (seg_local * n_prims * rec / 256.0 + pix_local * 12.0) / launches_per_step
-        flops_alg = seg_local * (n_prims * 20.0 + 120.0) / launches_per_step
-        achieved = bytes_alg / launch_s / 1e9
-        traffic = None
-        try:
-            t_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            e = t_all.get("%s/%s/%s" % (args.config, accel, args.precision))
-            if e and world == 1:
-                traffic = int((e["fetch_size_kb"] + e["write_size_kb"]) * 1024)
-        except (OSError, ValueError, KeyError):
-            pass
-        return {
-            "value": round(samples / (dt / steps) / 1e6, 3), "ms_per_step": round(dt / steps * 1e3, 4), "segments": segments,
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "kernel": "trace_kernel<%s,%s>" % (args.precision, "BVH" if accel == "bvh" else "flat scan + FP32 cull"),
-                "launch_ms": round(launch_s * 1e3, 4), "launches_per_step": launches_per_step, "algorithmic_bytes_per_launch": round(bytes_alg),
-                "note": "algorithmic bytes = S*N*REC/256 + 12*pixels (SURVEY.md 8d: what the reference's Hitlist scan must touch with a "
-                        "256-ray LDS tile); the scene is on-chip (scalar cache / L2), so HBM is not what binds this path; traffic = "
-                        "rocprofv3 FETCH_SIZE+WRITE_SIZE of this kernel from profiles/ (the write is the 24 B/sample buffer)",
-                "valu": {"achieved": round(flops_alg / launch_s / 1e12, 3), "peak": peak_t, "unit": "TFLOP/s",
-                         "frac": round(flops_alg / launch_s / 1e12 / peak_t, 5),
-                         "note": "reference-equivalent flops S*(20N+120) per SURVEY.md 8d over the FP64 vector peak; the FP32 cull / "
-                                 "BVH skip most of that work, so this can exceed 1 -- it measures work avoided, not ALU utilisation"}}}
+        res = {"value": round(samples / (dt / steps) / 1e6, 3), "ms_per_step": round(dt / steps * 1e3, 4), "segments": segments,
+               "segments_per_sample": round(segments / samples, 4),
+               "roofline": roofline(cfg_name, accel, args.precision, n_prims, launch_s, launches_per_step, counts, share=1.0 / world)}
+        if count and accel == "bvh":
+            res["aabb_tests_per_segment"] = round(counts["aabb_tests"] / max(1, counts["segments"]), 3)
+            res["prim_tests_per_segment"] = round(counts["prim_tests"] / max(1, counts["segments"]), 3)
+        if gather_ms is not None:
+            res["gather_ms"] = round(gather_ms, 4)
+        return res
 
-    main_accel = args.accel
-    res = measure(main_accel, args.steps, args.warmup, pipe)
-    serial = measure(main_accel, max(2, min(args.steps, 5)), 1, pipe1) if in_flight > 1 else None
-    other = None
-    if world == 1 and not args.single:
-        other_accel = "flat" if main_accel == "bvh" else "bvh"
-        other = measure(other_accel, max(2, min(args.steps, 5)), 1, pipe)
+    drv = InLibrary(flat, nx, ny) if in_library else OneGpu(flat, nx, ny, max(1, args.frames_in_flight) if world == 1 else 1)
+    res = measure(drv, args.accel, args.steps, args.warmup, cfg, nx, ny, ns, n_prims)
 
+    out = None
     if rank == 0:
-        samples = nx * ny * ns
         out = {
             "metric": "Msamples/sec (nx*ny*ns)", "value": res["value"], "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": ("%s: %dx%dx%dspp classic Cornell box (%d rectangles via Translate/RotateY/FlipNormals), depth 50, "
-                                    "seeded counter RNG; accel=%s; tiles dealt round-robin to %d GPU(s)" % (args.config, nx, ny, ns, n_prims, main_accel, world))
-                       if args.config == "CB" else
-                       ("%s: %dx%dx%dspp make-final (scene.clj:415-489; %d primitives), depth 50; accel=%s; %d GPU(s)" % (args.config, nx, ny, ns, n_prims, main_accel, world))
-                       if args.config == "FINAL" else
-                       "%s: %dx%dx%dspp Shirley cover scene n=%d (%d spheres%s), depth 50, thin-lens camera, "
-                       "seeded counter RNG; accel=%s; tiles dealt round-robin to %d GPU(s)" % (
-                           args.config, nx, ny, ns, n, n_prims, ", moving" if moving else "", main_accel, world),
-                       "nx": nx, "ny": ny, "ns": ns, "spheres": n_prims, "depth": 50, "accel": main_accel,
-                       "frames_in_flight": in_flight, "segments_per_sample": round(res["segments"] / samples, 4)},
+            "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": workload_text(cfg, nx, ny, ns, n_prims, args.accel, world), "nx": nx, "ny": ny, "ns": ns, "spheres": n_prims,
+                       "depth": 50, "accel": args.accel, "frames_in_flight": drv.slots, "segments_per_sample": res["segments_per_sample"],
+                       "launch_form": "one process per GPU (torch.distributed, RCCL gather)" if multi_proc else
+                                      ("one host process, rtmi_render_multi_device (in-library ncclGather)" if in_library else "one GPU")},
             "roofline": res["roofline"],
         }
-        if serial is not None:
-            # The roofline prices ONE launch of the dominant kernel.  With two frames in flight a launch is queued behind the
-            # previous frame's launch on the other stream, so its HIP-event interval covers the wait for CU slots as well as
-            # the run; the kernel's own duration is what the one-frame-in-flight steps (timed in this same run, same events)
-            # measure -- the roofline uses those, and the queued interval is reported beside it.
-            out["serial"] = {"value": serial["value"], "ms_per_step": serial["ms_per_step"], "steps": max(2, min(args.steps, 5)),
-                             "note": "the same steps with one frame in flight (no overlap between consecutive frames)"}
-            out["roofline"] = dict(serial["roofline"])
-            out["roofline"]["pipelined_launch_ms"] = res["roofline"]["launch_ms"]
-            out["roofline"]["note"] += ("; launch_ms / achieved are measured on the one-frame-in-flight steps of this run (`serial`): with "
-                                        "frames_in_flight = %d a launch waits for the previous frame's workgroups to vacate the CUs, and its "
-                                        "event interval (pipelined_launch_ms) includes that wait" % in_flight)
-        if other is not None:
-            out["other_accel"] = {"accel": other_accel, "value": other["value"], "ms_per_step": other["ms_per_step"], "roofline": other["roofline"]}
+        for k in ("aabb_tests_per_segment", "prim_tests_per_segment", "gather_ms"):
+            if k in res:
+                out[k] = res[k]
+        if rehearsal:
+            out["rehearsal"] = True
+            out["config"]["workload"] += " -- REHEARSAL: the %d replicas share %d device(s); control flow only, not a measurement" % (world, visible)
+    # ---- extras (N = 1 only, outside the timed region) -------------------------------------------------------------------
+    if world == 1 and extras and rank == 0:
+        if drv.slots == 1:
+            two = OneGpu(flat, nx, ny, 2)
+            p = measure(two, args.accel, max(2, min(args.steps, 5)), 2, cfg, nx, ny, ns, n_prims, count=False)
+            out["pipelined"] = {"value": p["value"], "ms_per_step": p["ms_per_step"], "frames_in_flight": 2,
+                                "note": "the same steps with two frames in flight on two streams: a frame's first workgroups fill the CUs the "
+                                        "previous frame's last deep paths leave idle; only for hosts that render frame after frame"}
+            two.pl.close()
+        for other in ("C2", "C4"):
+            if other == cfg:
+                continue
+            onx, ony, ons = CONFIGS[other][:3]
+            _, oflat = build_scene(r, other)
+            od = OneGpu(oflat, onx, ony, 1)
+            o = measure(od, args.accel, 10 if other == "C2" else 2, 2 if other == "C2" else 1, other, onx, ony, ons, oflat.n_prims)
+            out[other.lower()] = {"workload": workload_text(other, onx, ony, ons, oflat.n_prims, args.accel, 1), "value": o["value"],
+                                  "ms_per_step": o["ms_per_step"], "segments_per_sample": o["segments_per_sample"], "roofline": o["roofline"]}
+            od.pl.close()
+        if cfg in ("C1", "C2", "C2m", "CB", "FINAL"):  # the other acceleration structure where it finishes in seconds
+            other_accel = "flat" if args.accel == "bvh" else "bvh"
+            o = measure(drv, other_accel, max(2, min(args.steps, 5)), 1, cfg, nx, ny, ns, n_prims)
+            out["other_accel"] = {"accel": other_accel, "value": o["value"], "ms_per_step": o["ms_per_step"], "roofline": o["roofline"]}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(flat, nx, ny, ns)
+            out["cpu_baseline"] = cpu_baseline(scene, flat, nx, ny, ns)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi_proc:
         dist.barrier()
         dist.destroy_process_group()
 

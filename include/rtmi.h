@@ -91,10 +91,12 @@ const char *rtmi_last_error(void);
 const char *rtmi_backend_name(void); /* "hip-gfx950" */
 int rtmi_version(void);
 
-/* Binds a context to HIP device `device` (one process per GPU: pass LOCAL_RANK). */
+/* Binds a context to HIP device `device` (one process per GPU: pass LOCAL_RANK; one process for the node: one context per
+ * device, see rtmi_render_multi). */
 int rtmi_init(int device, uint32_t flags, rtmi_ctx **out_ctx);
 int rtmi_shutdown(rtmi_ctx *ctx);
-/* knobs: "accel" (RTMI_ACCEL_*), "workspace_bytes" (sample-buffer budget: a frame is rendered in as many sample passes as
+/* knobs: "accel" (RTMI_ACCEL_*; default RTMI_ACCEL_BVH -- bit-identical to the flat scan), "count_traversal" (0/1: the next
+ * renders run the counting instantiation of the BVH kernel, see rtmi_last_traversal_counters), "workspace_bytes" (sample-buffer budget: a frame is rendered in as many sample passes as
  * it takes), "blocks_per_cu" (cap on resident trace workgroups per CU; the launch never exceeds what stays resident),
  * "scan_variant" (flat scan: 0 LDS literal, 1 LDS pipelined, 2 scalar cache, 3 scalar cache + FP32 cull = default),
  * "lds_tile_bytes" (LDS variants), "timing" (0/1 = RTMI_FLAG_TIMING).
@@ -149,14 +151,19 @@ int rtmi_scene_destroy(rtmi_scene *scene);
  * samples of `color` (core.clj:17-41, depth as core.clj:20,45), mean, gamma 2, 8-bit (core.clj:52-57).
  * out_linear: (y1-y0)*(x1-x0)*3 doubles, the per-pixel mean BEFORE sqrt (for RMS parity), may be NULL;
  * out_rgb8: same shape uint8, trunc(min(255.99, 255.99*sqrt(mean))), NaN -> 0, may be NULL;
- * out_counters: {total-rays (core.clj:24), total-pixels (core.clj:47)} (metrics.clj:8-9), may be NULL.
+ * out_counters: {total-rays (core.clj:24), total-pixels (core.clj:47)} (metrics.clj:8-9) of the region's pixels, may be NULL.
+ * Only the 8x8 tiles that intersect the region are rendered.
  * Every random draw is the next value of the counter stream keyed (seed, j*nx+i, sample). */
 int rtmi_render(rtmi_scene *scene, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed, int32_t precision,
                 int32_t x0, int32_t y0, int32_t x1, int32_t y1,
                 double *out_linear, uint8_t *out_rgb8, uint64_t *out_counters);
 
-/* Same path with every buffer resident in HBM (device pointers), launched on `stream` (a hipStream_t,
- * NULL = the context's own stream); asynchronous.  d_out_linear holds doubles for both precisions. */
+/* Same path with every buffer resident in HBM (device pointers), launched on `stream` (a hipStream_t); asynchronous.
+ * stream = NULL means the CONTEXT'S OWN stream (created hipStreamNonBlocking), NOT the HIP default stream: work the caller
+ * has queued on any other stream -- including the legacy default stream, whose handle is also 0 -- is not ordered with it.
+ * A caller whose buffers are produced / consumed on another stream passes that stream's handle here (for the legacy
+ * default stream: hipStreamLegacy) or brackets the call with events.  A context's workspace belongs to one stream at a time.
+ * d_out_linear holds doubles for both precisions. */
 int rtmi_render_device(rtmi_scene *scene, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed, int32_t precision,
                        void *d_out_linear, void *d_out_rgb8, void *d_out_counters, void *stream);
 
@@ -174,6 +181,36 @@ int32_t rtmi_local_tiles(int32_t nx, int32_t ny, int32_t tile_first, int32_t til
  * tile r + k*world) -> dense row-major frame (doubles, may be NULL) + 8-bit frame (may be NULL). */
 int rtmi_assemble_device(rtmi_ctx *ctx, int32_t nx, int32_t ny, int32_t world, int32_t tiles_per_rank,
                          const void *d_gathered, void *d_out_linear, void *d_out_rgb8, void *stream);
+
+/* ---- one host process, several GPUs ---------------------------------------------------------------
+ * The reference's host is ONE JVM whose render loop fans out over a thread pool (cp/upmap, core.clj:100-108); the same
+ * single process reaches the 8 GPUs of a node through these entries: one context per device (rtmi_init), the scene
+ * replicated onto each (rtmi_scene_clone; it is tiny), the framebuffer's 8x8 tiles dealt round-robin (replica r renders
+ * global tiles r, r+n, ...: the reference's tiled-coords chunks, core.clj:59-71), ONE gather over xGMI to replica 0's
+ * device -- ncclGather on a communicator the library creates with ncclCommInitAll and owns (librccl is opened on first
+ * use; a single-GPU host never loads it) -- and replica 0 un-tiles / quantises.  Pixels are independent and the stream key is
+ * the global pixel index: the image is bit-identical to the single-device render.
+ * Replicas that share a device (to rehearse the control flow on a one-GPU host) are gathered by device copies instead. */
+/* Replicates `scene` onto `ctx` (another device): the library copied the caller's arrays at creation. */
+int rtmi_scene_clone(rtmi_scene *scene, rtmi_ctx *ctx, rtmi_scene **out_scene);
+/* Replaces core.clj:100-108 on n devices.  scenes[r] = replica r (each on its own context).  Host buffers as rtmi_render
+ * (whole frame); out_counters = {total-rays summed over the replicas, total-pixels}. */
+int rtmi_render_multi(int32_t n, rtmi_scene *const *scenes, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed,
+                      int32_t precision, double *out_linear, uint8_t *out_rgb8, uint64_t *out_counters);
+/* The same, asynchronous, outputs resident on replica 0's device (ordered on replica 0's context stream; every replica
+ * renders on its own context stream). */
+int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed,
+                             int32_t precision, void *d_out_linear, void *d_out_rgb8, void *d_out_counters);
+/* Milliseconds between the end of replica 0's own render and the end of the gather of the last rtmi_render_multi* on
+ * replica 0's context (HIP events on its stream): the transfer plus the wait for the slowest replica. */
+int rtmi_last_gather_ms(rtmi_ctx *ctx0, double *ms);
+
+/* The reference's third counter, metrics.clj:10 `aabb.intersection.total` (incremented once per AABB.hit?, hitable.clj:39),
+ * for the device's own tree: *out_aabb_tests = AABB slab tests, *out_prim_tests = exact primitive tests (leaves + the
+ * primitives kept out of the tree) of the context's most recent render.  Needs option "count_traversal" = 1 before that
+ * render (a separate kernel instantiation: the default kernel does not pay for the counting); synchronises on the render's
+ * stream.  The numbers depend on the tree the library built, not on the reference's random-axis tree. */
+int rtmi_last_traversal_counters(rtmi_ctx *ctx, uint64_t *out_aabb_tests, uint64_t *out_prim_tests);
 
 /* Total milliseconds of the trace-kernel launches of every render on this context since the previous call
  * (HIP events recorded on the launch stream around each launch; needs RTMI_FLAG_TIMING; synchronises on the

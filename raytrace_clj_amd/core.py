@@ -55,6 +55,13 @@ class Context:
         check(_ffi.lib().rtmi_last_trace_ms(self.handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def last_traversal_counters(self):
+        """(AABB slab tests, exact primitive tests) of the last render; needs set_option("count_traversal", 1) before it
+        (metrics.clj:10 aabb.intersection.total, for the device's own tree)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(_ffi.lib().rtmi_last_traversal_counters(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def close(self):
         if self.handle:
             _ffi.lib().rtmi_shutdown(self.handle)
@@ -110,6 +117,14 @@ class DeviceScene:
             wh = np.ascontiguousarray([[im.shape[1], im.shape[0]] for im in imgs], np.int32)
             rgb = np.ascontiguousarray(np.concatenate([im.reshape(-1) for im in imgs]), np.uint8)
             check(_ffi.lib().rtmi_scene_set_images(h, len(imgs), ptr(wh), ptr(rgb)))
+
+    def clone(self, ctx):
+        """the same scene replicated onto another context / device (rtmi_scene_clone)"""
+        h = C.c_void_p()
+        check(_ffi.lib().rtmi_scene_clone(self.handle, ctx.handle, C.byref(h)))
+        other = object.__new__(DeviceScene)
+        other.ctx, other.flat, other.handle = ctx, self.flat, h
+        return other
 
     def close(self):
         if self.handle:

@@ -10,6 +10,8 @@
 //     -> reduce kernel: per pixel, sum over s IN SAMPLE ORDER (core.clj:52 reduce mat/add), * 1/ns
 //     -> assemble kernel: tile-major -> dense frame, sqrt, *255.99, min, trunc (core.clj:54-56)
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types and prototypes only: librccl is opened at the first multi-device gather (dlopen), never linked
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -18,6 +20,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -72,6 +76,8 @@ struct TraceParams {
     int n_ptiles;          // number of LDS tiles the static spheres are cut into
     unsigned *queue;       // work queue head of this pass (zeroed before the launch): next unclaimed work item
     unsigned total_items;  // n_local_tiles * s_count * 64
+    int rx0, ry0, rx1, ry1; // output region (row 0 = top): pixels outside it are not traced (whole frame: 0, 0, nx, ny)
+    u64 *trav;             // COUNT instantiations: [0] += AABB slab tests (metrics aabb.intersection.total, hitable.clj:39), [1] += exact primitive tests
 };
 #ifndef RTMI_QUEUE_BLOCK
 #define RTMI_QUEUE_BLOCK 256
@@ -125,15 +131,15 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
 }
 __device__ inline void intersect_ext(SceneRef, int *, bool, Path<float> &, bool, float, float tmax, float &best_t, int &best_i) { best_t = tmax; best_i = -1; }
 
-template <typename R, bool MULTI, int VARIANT, bool EXT = false>
+template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false>
 __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, Path<R> &P,
-                                       bool active, R tmin, R tmax, R &best_t, int &best_i) {
+                                       bool active, R tmin, R tmax, R &best_t, int &best_i, unsigned *cnt = nullptr) {
     if (EXT) { intersect_ext(sc, reinterpret_cast<int *>(lds), VARIANT == SCAN_BVH, P, active, tmin, tmax, best_t, best_i); return; }
     best_t = tmax;
     best_i = -1;
     const R a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
     if (VARIANT == SCAN_BVH) { // RTMI_ACCEL_BVH; `lds` is the traversal stack
-        if (active) scan_bvh<R>(sc, reinterpret_cast<int *>(lds), P, a, tmin, best_t, best_i, [&]() { scan_cull_dispatch(sc, P, a, tmin, best_t, best_i); });
+        if (active) scan_bvh<R, COUNT>(sc, reinterpret_cast<int *>(lds), P, a, tmin, best_t, best_i, [&]() { scan_cull_dispatch(sc, P, a, tmin, best_t, best_i); }, cnt);
         return;
     }
     if (VARIANT == SCAN_SGPR_CULL) { // all primitives, original order; returns the original index
@@ -186,7 +192,7 @@ template <typename R> __device__ inline void start_sample(SceneRef sc, const Tra
     P.depth = tp.depth;
 }
 
-template <typename R, bool MULTI, int VARIANT, bool EXT = false>
+template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false>
 __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
     SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -210,6 +216,7 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
     bool exhausted = (total_items == 0);
     size_t out_idx = 0;
     unsigned nrays = 0;
+    unsigned ntrav[2] = {0u, 0u};
     const R tmin = R(0.001), tmax = Real<R>::tmax();
 
     RTMI_STAMP_DECL
@@ -238,7 +245,7 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
                 const int gtile = tp.tile_ids[tile_local];
                 const int x = (gtile % tp.tiles_x) * RTMI_TILE + (l & 7);
                 const int y = (gtile / tp.tiles_x) * RTMI_TILE + (l >> 3);
-                if (x < tp.nx && y < tp.ny) {
+                if (x >= tp.rx0 && x < tp.rx1 && y >= tp.ry0 && y < tp.ry1) {
                     start_sample<R>(sc, tp, x, tp.ny - 1 - y, s, P); // j = ny-1-y (core.clj:105)
                     out_idx = (size_t)m * 3;
                     alive = true;
@@ -252,7 +259,7 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
 
         // ---- one iteration of `color` for every live lane ---------------------------------------------
         R best_t; int best_i;
-        intersect_world<R, MULTI, VARIANT, EXT>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i);
+        intersect_world<R, MULTI, VARIANT, EXT, COUNT>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i, ntrav);
         RTMI_STAMP(1) // intersection
         if (alive) {
             ++nrays;
@@ -269,20 +276,26 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
     unsigned n = nrays;
     for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
     if (lane == 0 && n) atomicAdd(tp.counters, (u64)n);
+    if (COUNT) {
+        u64 a = ntrav[0], b = ntrav[1];
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+        if (lane == 0) { atomicAdd(tp.trav, a); atomicAdd(tp.trav + 1, b); }
+    }
 }
 
 // core.clj:52-53: (reduce mat/add) over the samples IN ORDER, then (mul (/ 1.0 nr)) on the last pass.
 template <typename R>
 __global__ void __launch_bounds__(kBlock) reduce_kernel(const R *__restrict__ samples, R *__restrict__ accum, double *__restrict__ tiles_linear,
                                                         const int *__restrict__ tile_ids, int tiles_x, int nx, int ny, int n_local_tiles,
-                                                        int s_begin, int s_count, int ns, u64 *counters, u64 n_valid_pixels) {
+                                                        int s_begin, int s_count, int ns, u64 *counters, u64 n_valid_pixels,
+                                                        int rx0, int ry0, int rx1, int ry1) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid == 0 && counters && s_begin + s_count >= ns) counters[1] = n_valid_pixels; // metrics total-pixels, core.clj:47
     if (gid >= (long long)n_local_tiles * 64) return;
     const int tile_local = (int)(gid >> 6), l = (int)(gid & 63);
     const int gtile = tile_ids[tile_local];
     const int x = (gtile % tiles_x) * RTMI_TILE + (l & 7), y = (gtile / tiles_x) * RTMI_TILE + (l >> 3);
-    const bool valid = x < nx && y < ny;
+    const bool valid = x >= rx0 && x < rx1 && y >= ry0 && y < ry1;
     R r = R(0), g = R(0), b = R(0);
     if (valid) {
         if (s_begin > 0) { r = accum[gid * 3]; g = accum[gid * 3 + 1]; b = accum[gid * 3 + 2]; }
@@ -305,7 +318,7 @@ __global__ void __launch_bounds__(kBlock) reduce_kernel(const R *__restrict__ sa
 // core.clj:54-56 + the y-flipped store of core.clj:105-106 (tiles already hold output rows).
 // gathered[r][k][64][3]: rank r's k-th tile is global tile r + k*world.
 template <typename R>
-__global__ void __launch_bounds__(kBlock) assemble_kernel(const double *__restrict__ gathered, int world, int tiles_per_rank, int tiles_x,
+__global__ void __launch_bounds__(kBlock) assemble_kernel(const double *__restrict__ gathered, int world, size_t rank_stride, int tiles_x,
                                                           int nx, int ny, double *__restrict__ out_linear, unsigned char *__restrict__ out_rgb8) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)nx * ny) return;
@@ -313,7 +326,7 @@ __global__ void __launch_bounds__(kBlock) assemble_kernel(const double *__restri
     const int gtile = (y / RTMI_TILE) * tiles_x + (x / RTMI_TILE);
     const int r = gtile % world, k = gtile / world;
     const int l = (y % RTMI_TILE) * RTMI_TILE + (x % RTMI_TILE);
-    const double *p = gathered + (((size_t)r * tiles_per_rank + k) * 64 + l) * 3;
+    const double *p = gathered + (size_t)r * rank_stride + ((size_t)k * 64 + l) * 3; // rank_stride: doubles per rank record
     for (int c = 0; c < 3; ++c) {
         const double m = p[c];
         if (out_linear) out_linear[gid * 3 + c] = m;
@@ -324,6 +337,38 @@ __global__ void __launch_bounds__(kBlock) assemble_kernel(const double *__restri
             if (q == q) { const R mq = q < R(255.99) ? q : R(255.99); o = (unsigned char)(int)mq; }
             out_rgb8[gid * 3 + c] = o;
         }
+    }
+}
+
+// The same for a rectangular window of tiles [tx0, tx0+wtx) x [ty0, ...) rendered for the output region [x0, x0+w) x [y0, y0+h):
+// tiles[k][64][3], k row-major over the window; writes the dense w x h region.
+template <typename R>
+__global__ void __launch_bounds__(kBlock) assemble_region_kernel(const double *__restrict__ tiles, int tx0, int ty0, int wtx, int x0, int y0, int w, int h,
+                                                                 double *__restrict__ out_linear, unsigned char *__restrict__ out_rgb8) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)w * h) return;
+    const int x = x0 + (int)(gid % w), y = y0 + (int)(gid / w);
+    const int k = (y / RTMI_TILE - ty0) * wtx + (x / RTMI_TILE - tx0);
+    const int l = (y % RTMI_TILE) * RTMI_TILE + (x % RTMI_TILE);
+    const double *p = tiles + ((size_t)k * 64 + l) * 3;
+    for (int c = 0; c < 3; ++c) {
+        const double m = p[c];
+        if (out_linear) out_linear[gid * 3 + c] = m;
+        if (out_rgb8) {
+            const R q = Real<R>::sqrt_((R)m) * R(255.99);
+            unsigned char o = 0;
+            if (q == q) { const R mq = q < R(255.99) ? q : R(255.99); o = (unsigned char)(int)mq; }
+            out_rgb8[gid * 3 + c] = o;
+        }
+    }
+}
+
+// multi-device render: every rank's record ends with its two metrics counters; out = their sums
+__global__ void sum_counters_kernel(const u64 *gathered, int world, size_t rank_stride_u64, size_t off_u64, u64 *out) {
+    if (threadIdx.x < 2) {
+        u64 acc = 0;
+        for (int r = 0; r < world; ++r) acc += gathered[(size_t)r * rank_stride_u64 + off_u64 + threadIdx.x];
+        out[threadIdx.x] = acc;
     }
 }
 
@@ -494,14 +539,19 @@ struct rtmi_ctx {
     std::string arch;
     int blocks_per_cu = 8; // workgroups per CU in the persistent grid (4 resident; the rest start as others drain: shorter tail)
     int64_t workspace_bytes = (int64_t)8 << 30;
-    int accel = RTMI_ACCEL_FLAT;
+    int accel = RTMI_ACCEL_BVH; // bit-identical to the flat Hitlist scan and what every reference scene builds (scene.clj:332: make-bvh)
     int scan_variant = SCAN_SGPR_CULL;
     int max_lds_bytes = 64 * 1024 - 64; // static-sphere LDS tile budget per workgroup
     // workspace
     DevBuf samples, accum, tiles, tile_ids, counters, scratch_lin;
+    DevBuf multi; // rtmi_render_multi*: this replica's record (tiles + counters); on replica 0 the gathered records of all replicas
+    hipEvent_t ev_done = nullptr, ev_g0 = nullptr, ev_g1 = nullptr; // multi-device: render finished / gather interval on replica 0
+    bool have_gather = false;
     int last_grid = 0; // workgroups of the last trace launch (diagnostics)
     std::vector<int> tile_ids_host;
-    int tile_key[4] = {-1, -1, -1, -1};
+    int tile_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    int count_traversal = 0;      // option "count_traversal": run the COUNT instantiation of the BVH kernels
+    hipStream_t last_stream = nullptr; // stream of the most recent render (rtmi_last_traversal_counters synchronises on it)
     long long tile_valid_pixels = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -519,6 +569,14 @@ struct rtmi_scene {
     int max_image = -1;       // highest ImageMap index: rtmi_scene_set_images must cover it
     bool have_perlin = false;
     std::vector<int> host_kind; // primitive kinds (boundary flag removed), for argument checks
+    // the caller's arrays, copied at creation (the library keeps no host POINTERS): what rtmi_scene_clone replicates
+    struct Args {
+        std::vector<int32_t> prim_kind, prim_mat, mat_kind, mat_tex, tex_kind, tex_child, prim_flip, prim_xform, xform_kind, perm, media_calls, image_wh;
+        std::vector<double> prim_geom, mat_param, tex_param, cam, xform_param, perlin_vec;
+        std::vector<uint8_t> image_rgb;
+        int cam_kind = 0;
+        bool has_media_calls = false;
+    } args;
 };
 
 namespace {
@@ -549,26 +607,31 @@ void lds_plan(const rtmi_ctx *c, int n_static, size_t real_bytes, int *prims_per
 int tiles_x_of(int nx) { return (nx + RTMI_TILE - 1) / RTMI_TILE; }
 int tiles_y_of(int ny) { return (ny + RTMI_TILE - 1) / RTMI_TILE; }
 
-int ensure_tile_ids(rtmi_ctx *c, int nx, int ny, int first, int stride, hipStream_t st, int *n_local) {
+// Local tile list of a render: global tiles first, first+stride, ... that intersect the output region rg = {x0, y0, x1, y1}.
+int ensure_tile_ids(rtmi_ctx *c, int nx, int ny, int first, int stride, const int *rg, hipStream_t st, int *n_local) {
     const int ntiles = tiles_x_of(nx) * tiles_y_of(ny);
-    const int nl = first < ntiles ? (ntiles - first - 1) / stride + 1 : 0;
-    *n_local = nl;
-    if (c->tile_key[0] == nx && c->tile_key[1] == ny && c->tile_key[2] == first && c->tile_key[3] == stride) return RTMI_OK;
-    c->tile_ids_host.resize((size_t)std::max(nl, 1));
+    const int key[8] = {nx, ny, first, stride, rg[0], rg[1], rg[2], rg[3]};
+    if (!std::memcmp(key, c->tile_key, sizeof key)) { *n_local = (int)c->tile_ids_host.size(); return RTMI_OK; }
     const int tx_n = tiles_x_of(nx);
+    const bool whole = rg[0] <= 0 && rg[1] <= 0 && rg[2] >= nx && rg[3] >= ny;
+    c->tile_ids_host.clear();
     long long valid = 0;
-    for (int k = 0; k < nl; ++k) {
-        const int g = first + k * stride;
-        c->tile_ids_host[(size_t)k] = g;
-        const int w = std::min(RTMI_TILE, nx - (g % tx_n) * RTMI_TILE), h = std::min(RTMI_TILE, ny - (g / tx_n) * RTMI_TILE);
-        valid += (long long)w * h;
+    for (int g = first; g < ntiles; g += stride) {
+        const int px0 = (g % tx_n) * RTMI_TILE, py0 = (g / tx_n) * RTMI_TILE;
+        const int ax0 = std::max(px0, rg[0]), ay0 = std::max(py0, rg[1]);
+        const int ax1 = std::min(std::min(px0 + RTMI_TILE, nx), rg[2]), ay1 = std::min(std::min(py0 + RTMI_TILE, ny), rg[3]);
+        if (ax1 <= ax0 || ay1 <= ay0) { if (whole) c->tile_ids_host.push_back(g); continue; } // (cannot happen for the whole frame)
+        c->tile_ids_host.push_back(g);
+        valid += (long long)(ax1 - ax0) * (ay1 - ay0);
     }
+    const int nl = (int)c->tile_ids_host.size();
+    *n_local = nl;
     c->tile_valid_pixels = valid;
     int rc = c->tile_ids.ensure((size_t)std::max(nl, 1) * sizeof(int));
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(c->tile_ids.p, c->tile_ids_host.data(), (size_t)nl * sizeof(int), hipMemcpyHostToDevice, st));
+    if (nl) HIP_TRY(hipMemcpyAsync(c->tile_ids.p, c->tile_ids_host.data(), (size_t)nl * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st)); // tile_ids_host may be rewritten by the next call
-    c->tile_key[0] = nx; c->tile_key[1] = ny; c->tile_key[2] = first; c->tile_key[3] = stride;
+    std::memcpy(c->tile_key, key, sizeof key);
     return RTMI_OK;
 }
 
@@ -586,16 +649,20 @@ int next_event_pair(rtmi_ctx *c, hipEvent_t *a, hipEvent_t *b) {
 }
 
 template <typename R>
-int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t seed, int first, int stride, void *d_tiles_linear,
+int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t seed, int first, int stride, const int *rg, void *d_tiles_linear,
                       void *d_counters, hipStream_t st) {
     rtmi_ctx *c = s->ctx;
     int n_local = 0;
-    int rc = ensure_tile_ids(c, nx, ny, first, stride, st, &n_local);
+    const int whole[4] = {0, 0, nx, ny};
+    if (!rg) rg = whole;
+    int rc = ensure_tile_ids(c, nx, ny, first, stride, rg, st, &n_local);
+    if (rc) return rc;
+    c->last_stream = st;
+    rc = c->counters.ensure(8 * sizeof(u64)); // [0..1] the metrics when the caller passes no buffer, [2] the work-queue head, [3..4] traversal counters
     if (rc) return rc;
     if (d_counters) HIP_TRY(hipMemsetAsync(d_counters, 0, 2 * sizeof(u64), st));
+    HIP_TRY(hipMemsetAsync(reinterpret_cast<u64 *>(c->counters.p) + 3, 0, 2 * sizeof(u64), st));
     if (n_local == 0) return RTMI_OK;
-    rc = c->counters.ensure(4 * sizeof(u64)); // [0..1] the metrics when the caller passes no buffer, [2] the work-queue head
-    if (rc) return rc;
     u64 *cnt = d_counters ? reinterpret_cast<u64 *>(d_counters) : reinterpret_cast<u64 *>(c->counters.p);
     unsigned *queue = reinterpret_cast<unsigned *>(reinterpret_cast<u64 *>(c->counters.p) + 2);
 
@@ -630,6 +697,8 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             HIP_TRY(hipEventRecord(e0, st));
         }
         tp.queue = queue; tp.total_items = (unsigned)((long long)n_local * s_count * 64);
+        tp.rx0 = std::max(rg[0], 0); tp.ry0 = std::max(rg[1], 0); tp.rx1 = std::min(rg[2], nx); tp.ry1 = std::min(rg[3], ny);
+        tp.trav = reinterpret_cast<u64 *>(c->counters.p) + 3;
         HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned), st));
         const int variant = c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant;
         void (*kern)(ScenePtr, TraceParams) = nullptr;
@@ -640,7 +709,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             else kern = trace_kernel<double, false, SCAN_SGPR_CULL, true>;
         } else
         switch (variant) {
-        case SCAN_BVH: kern = trace_kernel<R, false, SCAN_BVH>; dyn_lds = bvh_lds; break;
+        case SCAN_BVH: kern = c->count_traversal ? trace_kernel<R, false, SCAN_BVH, false, true> : trace_kernel<R, false, SCAN_BVH>; dyn_lds = bvh_lds; break;
         case SCAN_SGPR_CULL: kern = trace_kernel<R, false, SCAN_SGPR_CULL>; break;
         case SCAN_SGPR: kern = trace_kernel<R, false, SCAN_SGPR>; break;
         case SCAN_LDS_PIPE: kern = multi ? trace_kernel<R, true, SCAN_LDS_PIPE> : trace_kernel<R, false, SCAN_LDS_PIPE>; dyn_lds = lds_bytes; break;
@@ -658,7 +727,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         hipLaunchKernelGGL((reduce_kernel<R>), dim3((unsigned)((npx + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                            reinterpret_cast<const R *>(c->samples.p), reinterpret_cast<R *>(c->accum.p),
                            reinterpret_cast<double *>(d_tiles_linear), reinterpret_cast<const int *>(c->tile_ids.p), tiles_x_of(nx), nx, ny,
-                           n_local, s_begin, s_count, ns, d_counters ? cnt : nullptr, (u64)c->tile_valid_pixels);
+                           n_local, s_begin, s_count, ns, d_counters ? cnt : nullptr, (u64)c->tile_valid_pixels, tp.rx0, tp.ry0, tp.rx1, tp.ry1);
         HIP_TRY(hipGetLastError());
     }
 #ifdef RTMI_STAMPS
@@ -945,7 +1014,7 @@ int check_render_args(rtmi_scene *s, int nx, int ny, int ns, int depth, int prec
 // ---- library / context -------------------------------------------------------------------------------
 RTMI_EXPORT const char *rtmi_last_error(void) { return g_err.c_str(); }
 RTMI_EXPORT const char *rtmi_backend_name(void) { return "hip-gfx950"; }
-RTMI_EXPORT int rtmi_version(void) { return 100; }
+RTMI_EXPORT int rtmi_version(void) { return 200; }
 RTMI_EXPORT uint64_t rtmi_sample_key(uint64_t seed, uint64_t pixel, uint64_t sample) { return sample_key(seed, pixel, sample); }
 
 RTMI_EXPORT int rtmi_init(int device, uint32_t flags, rtmi_ctx **out_ctx) {
@@ -979,7 +1048,8 @@ RTMI_EXPORT int rtmi_shutdown(rtmi_ctx *c) {
     if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->samples.release(); c->accum.release(); c->tiles.release(); c->tile_ids.release(); c->counters.release(); c->scratch_lin.release();
+    c->samples.release(); c->accum.release(); c->tiles.release(); c->tile_ids.release(); c->counters.release(); c->scratch_lin.release(); c->multi.release();
+    for (hipEvent_t e : {c->ev_done, c->ev_g0, c->ev_g1}) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     (void)hipStreamDestroy(c->stream);
     c->magic = 0;
@@ -995,6 +1065,7 @@ RTMI_EXPORT int rtmi_set_option(rtmi_ctx *c, const char *name, int64_t value) {
     if (!std::strcmp(name, "lds_tile_bytes")) { if (value < 1024 || value > 64 * 1024 - 64) return fail(RTMI_E_ARG, "lds_tile_bytes out of range"); c->max_lds_bytes = (int)value; return RTMI_OK; }
     if (!std::strcmp(name, "timing")) { if (value) c->flags |= RTMI_FLAG_TIMING; else c->flags &= ~RTMI_FLAG_TIMING; return RTMI_OK; }
     if (!std::strcmp(name, "scan_variant")) { if (value < 0 || value > 3) return fail(RTMI_E_ARG, "scan_variant must be 0..3"); c->scan_variant = (int)value; return RTMI_OK; }
+    if (!std::strcmp(name, "count_traversal")) { c->count_traversal = value ? 1 : 0; return RTMI_OK; }
     if (!std::strcmp(name, "accel")) {
         if (value == RTMI_ACCEL_FLAT || value == RTMI_ACCEL_BVH) { c->accel = (int)value; return RTMI_OK; }
         return fail(RTMI_E_UNSUPPORTED, "accel %lld is not available in this build", (long long)value);
@@ -1078,6 +1149,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
         if (!is_boundary) n_world = i + 1;
         if (prim_mat[i] < 0 || prim_mat[i] >= n_mats) return fail(RTMI_E_ARG, "primitive %d: material index %d invalid", i, prim_mat[i]);
         pk[(size_t)i] = kind; pm[(size_t)i] = prim_mat[i];
+        if (mat_kind[prim_mat[i]] == RTMI_MAT_ISOTROPIC) has_ext = true; // Isotropic.scatter (shader.clj:129-138) is compiled into the EXT kernels only
         if (kind == RTMI_PRIM_MEDIUM) {
             const double *mg = prim_geom + (size_t)i * RTMI_PRIM_STRIDE;
             const int fb = (int)mg[1], nb = (int)mg[2];
@@ -1314,6 +1386,18 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
         s->d_dev = (ScenePtr)dp;
     }
     if (rc) { rtmi_scene_destroy(s); return rc; }
+    {
+        rtmi_scene::Args &A = s->args;
+        A.prim_kind.assign(prim_kind, prim_kind + n_prims); A.prim_mat.assign(prim_mat, prim_mat + n_prims);
+        A.prim_geom.assign(prim_geom, prim_geom + (size_t)n_prims * RTMI_PRIM_STRIDE);
+        A.mat_kind.assign(mat_kind, mat_kind + n_mats); A.mat_tex.assign(mat_tex, mat_tex + n_mats); A.mat_param.assign(mat_param, mat_param + n_mats);
+        A.tex_kind.assign(tex_kind, tex_kind + n_tex); A.tex_param.assign(tex_param, tex_param + (size_t)n_tex * RTMI_TEX_STRIDE);
+        A.tex_child.assign(tex_child, tex_child + 2 * (size_t)n_tex);
+        A.cam.assign(cam, cam + 24); A.cam_kind = cam_kind;
+        if (prim_flip) A.prim_flip.assign(prim_flip, prim_flip + n_prims);
+        if (prim_xform) A.prim_xform.assign(prim_xform, prim_xform + 2 * (size_t)n_prims);
+        if (n_xforms > 0) { A.xform_kind.assign(xform_kind, xform_kind + n_xforms); A.xform_param.assign(xform_param, xform_param + 3 * (size_t)n_xforms); }
+    }
     *out_scene = s;
     return RTMI_OK;
 }
@@ -1344,6 +1428,7 @@ RTMI_EXPORT int rtmi_scene_set_perlin(rtmi_scene *s, const double *vectors, cons
     if (!rc) rc = upload(s, p, &s->dev.perlin_perm);
     if (rc) return rc;
     s->have_perlin = true;
+    s->args.perlin_vec = v; s->args.perm.assign(perm, perm + 768);
     return reupload_descriptor(s);
 }
 
@@ -1354,6 +1439,7 @@ RTMI_EXPORT int rtmi_scene_set_media_calls(rtmi_scene *s, int32_t n_calls, const
         if (calls[k] < 0 || calls[k] >= s->n_prims || s->host_kind[(size_t)calls[k]] != RTMI_PRIM_MEDIUM) return fail(RTMI_E_ARG, "calls[%d] = %d is not a medium primitive", k, calls[k]);
     s->dev.n_media = n_calls;
     for (int k = 0; k < n_calls; ++k) s->dev.media_idx[k] = calls[k];
+    s->args.media_calls.assign(calls, calls + n_calls); s->args.has_media_calls = true;
     HIP_TRY(hipSetDevice(s->ctx->device));
     return reupload_descriptor(s);
 }
@@ -1377,6 +1463,7 @@ RTMI_EXPORT int rtmi_scene_set_images(rtmi_scene *s, int32_t n_images, const int
     if (!rc) rc = upload(s, px, &s->dev.image_rgb);
     if (rc) return rc;
     s->dev.n_images = n_images;
+    s->args.image_wh = whv; s->args.image_rgb = px;
     return reupload_descriptor(s);
 }
 
@@ -1404,8 +1491,8 @@ RTMI_EXPORT int rtmi_render_tiles_device(rtmi_scene *s, int32_t nx, int32_t ny, 
     if (!d_tiles_linear) return fail(RTMI_E_ARG, "d_tiles_linear is NULL");
     HIP_TRY(hipSetDevice(s->ctx->device));
     hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : s->ctx->stream;
-    if (precision == RTMI_F64) return render_tiles_impl<double>(s, nx, ny, ns, depth, seed, tile_first, tile_stride, d_tiles_linear, d_out_counters, st);
-    return render_tiles_impl<float>(s, nx, ny, ns, depth, seed, tile_first, tile_stride, d_tiles_linear, d_out_counters, st);
+    if (precision == RTMI_F64) return render_tiles_impl<double>(s, nx, ny, ns, depth, seed, tile_first, tile_stride, nullptr, d_tiles_linear, d_out_counters, st);
+    return render_tiles_impl<float>(s, nx, ny, ns, depth, seed, tile_first, tile_stride, nullptr, d_tiles_linear, d_out_counters, st);
 }
 
 RTMI_EXPORT int rtmi_assemble_device(rtmi_ctx *c, int32_t nx, int32_t ny, int32_t world, int32_t tiles_per_rank, const void *d_gathered,
@@ -1419,7 +1506,7 @@ RTMI_EXPORT int rtmi_assemble_device(rtmi_ctx *c, int32_t nx, int32_t ny, int32_
     const long long npx = (long long)nx * ny;
     // the 8-bit quantiser always runs in double on the double mean: both precisions share it
     hipLaunchKernelGGL((assemble_kernel<double>), dim3((unsigned)((npx + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                       reinterpret_cast<const double *>(d_gathered), world, tiles_per_rank, tiles_x_of(nx), nx, ny,
+                       reinterpret_cast<const double *>(d_gathered), world, (size_t)tiles_per_rank * 192, tiles_x_of(nx), nx, ny,
                        reinterpret_cast<double *>(d_out_linear), reinterpret_cast<unsigned char *>(d_out_rgb8));
     HIP_TRY(hipGetLastError());
     return RTMI_OK;
@@ -1447,27 +1534,240 @@ RTMI_EXPORT int rtmi_render(rtmi_scene *s, int32_t nx, int32_t ny, int32_t ns, i
     if (x0 < 0 || y0 < 0 || x1 > nx || y1 > ny || x1 <= x0 || y1 <= y0) return fail(RTMI_E_ARG, "region [%d,%d)x[%d,%d) outside %dx%d", x0, x1, y0, y1, nx, ny);
     rtmi_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t npx = (size_t)nx * ny;
-    // the host entry point renders the whole frame on the device and copies the region out
+    // only the 8x8 tiles that intersect the region are rendered, and only the region's pixels in them are traced: both
+    // counters describe exactly the region (a 16x8 spot check of a 1920x1080 frame costs 2 tiles, not 32400)
+    const int w = x1 - x0, h = y1 - y0;
+    const int tx0 = x0 / RTMI_TILE, ty0 = y0 / RTMI_TILE, tx1 = (x1 + RTMI_TILE - 1) / RTMI_TILE, ty1 = (y1 + RTMI_TILE - 1) / RTMI_TILE;
+    const int wtx = tx1 - tx0, nwin = wtx * (ty1 - ty0);
+    const size_t npx = (size_t)w * h;
+    rc = c->tiles.ensure((size_t)nwin * 64 * 3 * sizeof(double));
+    if (rc) return rc;
     rc = c->scratch_lin.ensure(npx * 3 * sizeof(double) + npx * 3 + 2 * sizeof(u64) + 64);
     if (rc) return rc;
     char *base = reinterpret_cast<char *>(c->scratch_lin.p);
     double *d_lin = reinterpret_cast<double *>(base);
     u64 *d_cnt = reinterpret_cast<u64 *>(base + npx * 3 * sizeof(double));
     unsigned char *d_q = reinterpret_cast<unsigned char *>(base + npx * 3 * sizeof(double) + 2 * sizeof(u64));
-    rc = rtmi_render_device(s, nx, ny, ns, depth, seed, precision, d_lin, d_q, d_cnt, nullptr);
+    const int rg[4] = {x0, y0, x1, y1};
+    hipStream_t st = c->stream;
+    if (precision == RTMI_F64) rc = render_tiles_impl<double>(s, nx, ny, ns, depth, seed, 0, 1, rg, c->tiles.p, d_cnt, st);
+    else rc = render_tiles_impl<float>(s, nx, ny, ns, depth, seed, 0, 1, rg, c->tiles.p, d_cnt, st);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const int w = x1 - x0, h = y1 - y0;
-    if (out_linear)
-        HIP_TRY(hipMemcpy2D(out_linear, (size_t)w * 3 * sizeof(double), d_lin + ((size_t)y0 * nx + x0) * 3, (size_t)nx * 3 * sizeof(double),
-                            (size_t)w * 3 * sizeof(double), (size_t)h, hipMemcpyDeviceToHost));
-    if (out_rgb8)
-        HIP_TRY(hipMemcpy2D(out_rgb8, (size_t)w * 3, d_q + ((size_t)y0 * nx + x0) * 3, (size_t)nx * 3, (size_t)w * 3, (size_t)h, hipMemcpyDeviceToHost));
-    if (out_counters) {
-        HIP_TRY(hipMemcpy(out_counters, d_cnt, 2 * sizeof(u64), hipMemcpyDeviceToHost));
-        out_counters[1] = (uint64_t)w * (uint64_t)h;
+    hipLaunchKernelGGL((assemble_region_kernel<double>), dim3((unsigned)((npx + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       reinterpret_cast<const double *>(c->tiles.p), tx0, ty0, wtx, x0, y0, w, h, d_lin, d_q);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    if (out_linear) HIP_TRY(hipMemcpy(out_linear, d_lin, npx * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_rgb8) HIP_TRY(hipMemcpy(out_rgb8, d_q, npx * 3, hipMemcpyDeviceToHost));
+    if (out_counters) HIP_TRY(hipMemcpy(out_counters, d_cnt, 2 * sizeof(u64), hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+// ---- one host process, several GPUs (the reference's host is ONE JVM: core.clj:100-108) ---------------------------------
+RTMI_EXPORT int rtmi_scene_clone(rtmi_scene *src, rtmi_ctx *ctx, rtmi_scene **out_scene) {
+    if (!scene_ok(src)) return fail(RTMI_E_STATE, "invalid scene handle");
+    if (!ctx_ok(ctx)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (!out_scene) return fail(RTMI_E_ARG, "out_scene is NULL");
+    const rtmi_scene::Args &A = src->args;
+    rtmi_scene *s = nullptr;
+    int rc = rtmi_scene_create_ex(ctx, src->n_prims, A.prim_kind.data(), A.prim_geom.data(), A.prim_mat.data(), src->n_mats, A.mat_kind.data(), A.mat_tex.data(),
+                                  A.mat_param.data(), src->n_tex, A.tex_kind.data(), A.tex_param.data(), A.tex_child.data(), A.cam_kind, A.cam.data(),
+                                  A.prim_flip.empty() ? nullptr : A.prim_flip.data(), A.prim_xform.empty() ? nullptr : A.prim_xform.data(),
+                                  (int32_t)A.xform_kind.size(), A.xform_kind.empty() ? nullptr : A.xform_kind.data(),
+                                  A.xform_param.empty() ? nullptr : A.xform_param.data(), &s);
+    if (rc) return rc;
+    if (!rc && !A.perlin_vec.empty()) rc = rtmi_scene_set_perlin(s, A.perlin_vec.data(), A.perm.data());
+    if (!rc && !A.image_wh.empty()) rc = rtmi_scene_set_images(s, (int32_t)(A.image_wh.size() / 2), A.image_wh.data(), A.image_rgb.data());
+    if (!rc && A.has_media_calls) rc = rtmi_scene_set_media_calls(s, (int32_t)A.media_calls.size(), A.media_calls.data());
+    if (rc) { const std::string keep = g_err; rtmi_scene_destroy(s); g_err = keep; return rc; }
+    *out_scene = s;
+    return RTMI_OK;
+}
+
+namespace {
+// RCCL, opened on first use: a single-GPU host never loads it.  (In a process that already maps an RCCL -- e.g. PyTorch's
+// bundled one -- dlopen by soname returns that copy.)
+struct Rccl {
+    bool tried = false;
+    void *h = nullptr;
+    std::string err;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+std::mutex g_multi_mu;
+Rccl g_rccl;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms; // one communicator set per device list (ncclCommInitAll), kept for the process
+
+bool rccl_load() {
+    Rccl &R = g_rccl;
+    if (R.tried) return R.h != nullptr;
+    R.tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        R.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (R.h) break;
     }
+    if (!R.h) { R.err = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); return false; }
+    bool ok = true;
+    auto sym = [&](const char *n) { void *p = dlsym(R.h, n); if (!p) { ok = false; R.err = std::string("librccl lacks ") + n; } return p; };
+    R.CommInitAll = reinterpret_cast<decltype(R.CommInitAll)>(sym("ncclCommInitAll"));
+    R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+    R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(sym("ncclGroupStart"));
+    R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(sym("ncclGroupEnd"));
+    R.Gather = reinterpret_cast<decltype(R.Gather)>(sym("ncclGather"));
+    R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { dlclose(R.h); R.h = nullptr; }
+    return ok;
+}
+
+#define NCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess) return fail(RTMI_E_DEVICE, "%s: %s", #expr, g_rccl.GetErrorString(r_));   \
+    } while (0)
+
+int ensure_event(hipEvent_t *e) {
+    if (!*e) HIP_TRY(hipEventCreate(e));
+    return RTMI_OK;
+}
+} // namespace
+
+RTMI_EXPORT int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed,
+                                         int32_t precision, void *d_out_linear, void *d_out_rgb8, void *d_out_counters) {
+    if (n <= 0 || n > 64 || !scenes) return fail(RTMI_E_ARG, "n must be 1..64 and scenes non-NULL");
+    for (int r = 0; r < n; ++r) {
+        int rc = check_render_args(scenes[r], nx, ny, ns, depth, precision);
+        if (rc) return rc;
+        for (int q = 0; q < r; ++q)
+            if (scenes[q]->ctx == scenes[r]->ctx) return fail(RTMI_E_ARG, "replicas %d and %d share a context (a context is not re-entrant: one per replica)", q, r);
+        if (scenes[r]->n_prims != scenes[0]->n_prims) return fail(RTMI_E_ARG, "replica %d is not a clone of replica 0", r);
+    }
+    std::lock_guard<std::mutex> lock(g_multi_mu);
+    const int ntiles = tiles_x_of(nx) * tiles_y_of(ny);
+    const int per = (ntiles + n - 1) / n;                  // every replica's record is padded to this many tiles
+    const size_t rec = (size_t)per * 192 + 2;              // 8-byte words per record: tiles [per][64][3] doubles + the two metrics counters
+    rtmi_ctx *c0 = scenes[0]->ctx;
+    std::vector<int> devs((size_t)n);
+    bool distinct = true;
+    for (int r = 0; r < n; ++r) {
+        devs[(size_t)r] = scenes[r]->ctx->device;
+        for (int q = 0; q < r; ++q) distinct = distinct && devs[(size_t)q] != devs[(size_t)r];
+    }
+    const char *force = std::getenv("RTMI_MULTI_GATHER"); // "copy": never RCCL (diagnostics)
+    const bool use_rccl = n > 1 && distinct && !(force && !std::strcmp(force, "copy"));
+    std::vector<ncclComm_t> *comms = nullptr;
+    if (use_rccl) {
+        if (!rccl_load()) return fail(RTMI_E_DEVICE, "multi-device gather needs RCCL: %s", g_rccl.err.c_str());
+        auto it = g_comms.find(devs);
+        if (it == g_comms.end()) {
+            std::vector<ncclComm_t> cs((size_t)n);
+            NCCL_TRY(g_rccl.CommInitAll(cs.data(), n, devs.data()));
+            it = g_comms.emplace(devs, std::move(cs)).first;
+        }
+        comms = &it->second;
+    }
+    // 1. every replica renders its tiles (r, r+n, ...) on its own device and stream, straight into its record
+    HIP_TRY(hipSetDevice(c0->device));
+    int rc = c0->multi.ensure((size_t)n * rec * 8);
+    if (rc) return rc;
+    char *gathered = reinterpret_cast<char *>(c0->multi.p);
+    std::vector<char *> recs((size_t)n);
+    for (int r = 0; r < n; ++r) {
+        rtmi_ctx *cr = scenes[r]->ctx;
+        HIP_TRY(hipSetDevice(cr->device));
+        if (r == 0) recs[0] = gathered; // in place: replica 0's record is the first of the gathered buffer
+        else { rc = cr->multi.ensure(rec * 8); if (rc) return rc; recs[(size_t)r] = reinterpret_cast<char *>(cr->multi.p); }
+        char *buf = recs[(size_t)r];
+        if (precision == RTMI_F64) rc = render_tiles_impl<double>(scenes[r], nx, ny, ns, depth, seed, r, n, nullptr, buf, buf + (size_t)per * 192 * 8, cr->stream);
+        else rc = render_tiles_impl<float>(scenes[r], nx, ny, ns, depth, seed, r, n, nullptr, buf, buf + (size_t)per * 192 * 8, cr->stream);
+        if (rc) return rc;
+        if (!use_rccl && r > 0) { rc = ensure_event(&cr->ev_done); if (rc) return rc; HIP_TRY(hipEventRecord(cr->ev_done, cr->stream)); }
+    }
+    // 2. ONE gather to replica 0's device
+    HIP_TRY(hipSetDevice(c0->device));
+    rc = ensure_event(&c0->ev_g0); if (!rc) rc = ensure_event(&c0->ev_g1);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c0->ev_g0, c0->stream));
+    if (use_rccl) {
+        NCCL_TRY(g_rccl.GroupStart());
+        for (int r = 0; r < n; ++r) {
+            const ncclResult_t e = g_rccl.Gather(recs[(size_t)r], r == 0 ? gathered : nullptr, rec, ncclUint64, 0, (*comms)[(size_t)r], scenes[r]->ctx->stream);
+            if (e != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(RTMI_E_DEVICE, "ncclGather(rank %d): %s", r, g_rccl.GetErrorString(e)); }
+        }
+        NCCL_TRY(g_rccl.GroupEnd());
+    } else {
+        for (int r = 1; r < n; ++r) { // replicas sharing a device (rehearsal on a one-GPU host), or RTMI_MULTI_GATHER=copy: plain copies on replica 0's stream
+            rtmi_ctx *cr = scenes[r]->ctx;
+            HIP_TRY(hipStreamWaitEvent(c0->stream, cr->ev_done, 0));
+            if (cr->device == c0->device) HIP_TRY(hipMemcpyAsync(gathered + (size_t)r * rec * 8, recs[(size_t)r], rec * 8, hipMemcpyDeviceToDevice, c0->stream));
+            else HIP_TRY(hipMemcpyPeerAsync(gathered + (size_t)r * rec * 8, c0->device, recs[(size_t)r], cr->device, rec * 8, c0->stream));
+        }
+    }
+    HIP_TRY(hipEventRecord(c0->ev_g1, c0->stream));
+    c0->have_gather = true;
+    // 3. replica 0 un-tiles, quantises and sums the counters
+    if (d_out_linear || d_out_rgb8) {
+        const long long npx = (long long)nx * ny;
+        hipLaunchKernelGGL((assemble_kernel<double>), dim3((unsigned)((npx + kBlock - 1) / kBlock)), dim3(kBlock), 0, c0->stream,
+                           reinterpret_cast<const double *>(gathered), n, rec, tiles_x_of(nx), nx, ny,
+                           reinterpret_cast<double *>(d_out_linear), reinterpret_cast<unsigned char *>(d_out_rgb8));
+        HIP_TRY(hipGetLastError());
+    }
+    if (d_out_counters) {
+        hipLaunchKernelGGL(sum_counters_kernel, dim3(1), dim3(64), 0, c0->stream, reinterpret_cast<const u64 *>(gathered), n, rec, (size_t)per * 192,
+                           reinterpret_cast<u64 *>(d_out_counters));
+        HIP_TRY(hipGetLastError());
+    }
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_render_multi(int32_t n, rtmi_scene *const *scenes, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed, int32_t precision,
+                                  double *out_linear, uint8_t *out_rgb8, uint64_t *out_counters) {
+    if (n <= 0 || !scenes || !scene_ok(scenes[0])) return fail(RTMI_E_ARG, "bad replica list");
+    rtmi_ctx *c0 = scenes[0]->ctx;
+    HIP_TRY(hipSetDevice(c0->device));
+    const size_t npx = (size_t)nx * (size_t)ny;
+    int rc = c0->scratch_lin.ensure(npx * 3 * sizeof(double) + npx * 3 + 2 * sizeof(u64) + 64);
+    if (rc) return rc;
+    char *base = reinterpret_cast<char *>(c0->scratch_lin.p);
+    double *d_lin = reinterpret_cast<double *>(base);
+    u64 *d_cnt = reinterpret_cast<u64 *>(base + npx * 3 * sizeof(double));
+    unsigned char *d_q = reinterpret_cast<unsigned char *>(base + npx * 3 * sizeof(double) + 2 * sizeof(u64));
+    rc = rtmi_render_multi_device(n, scenes, nx, ny, ns, depth, seed, precision, d_lin, d_q, d_cnt);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c0->device));
+    HIP_TRY(hipStreamSynchronize(c0->stream)); // ordered after every replica's render through the gather
+    if (out_linear) HIP_TRY(hipMemcpy(out_linear, d_lin, npx * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_rgb8) HIP_TRY(hipMemcpy(out_rgb8, d_q, npx * 3, hipMemcpyDeviceToHost));
+    if (out_counters) HIP_TRY(hipMemcpy(out_counters, d_cnt, 2 * sizeof(u64), hipMemcpyDeviceToHost));
+    for (int r = 1; r < n; ++r) { HIP_TRY(hipSetDevice(scenes[r]->ctx->device)); HIP_TRY(hipStreamSynchronize(scenes[r]->ctx->stream)); }
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_last_gather_ms(rtmi_ctx *c, double *ms) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (!c->have_gather) return fail(RTMI_E_STATE, "no multi-device render on this context yet");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev_g1));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, c->ev_g0, c->ev_g1));
+    if (ms) *ms = t;
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_last_traversal_counters(rtmi_ctx *c, uint64_t *out_aabb_tests, uint64_t *out_prim_tests) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (!c->count_traversal) return fail(RTMI_E_STATE, "set option count_traversal = 1 before the render");
+    if (!c->counters.p) return fail(RTMI_E_STATE, "no render on this context yet");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->last_stream ? c->last_stream : c->stream));
+    u64 v[2] = {0, 0};
+    HIP_TRY(hipMemcpy(v, reinterpret_cast<u64 *>(c->counters.p) + 3, sizeof v, hipMemcpyDeviceToHost));
+    if (out_aabb_tests) *out_aabb_tests = v[0];
+    if (out_prim_tests) *out_prim_tests = v[1];
     return RTMI_OK;
 }
 

@@ -678,8 +678,8 @@ __device__ inline unsigned long long stamp_now() {
     return t;
 }
 #endif
-template <bool NODE16, typename Leaf, typename BestHi>
-__device__ inline void bvh_traverse_fmt(SceneRef sc, int *stack, const BvhRay &r, Leaf leaf, BestHi best) {
+template <bool NODE16, bool COUNT, typename Leaf, typename BestHi>
+__device__ inline void bvh_traverse_fmt(SceneRef sc, int *stack, const BvhRay &r, Leaf leaf, BestHi best, unsigned *cnt) {
     int node = sc.bvh_root; // inner node: byte offset of its record (>= 0); leaf: ~(primitive | moving << 30) (< 0)
     if (node == RTMI_BVH_EMPTY) return;
     const int stride = blockDim.x;
@@ -689,6 +689,7 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, int *stack, const BvhRay &r
     float best_hi = best();
     while (node != RTMI_BVH_EMPTY) {
         while (node >= 0 && node != RTMI_BVH_EMPTY) { // inner node: both child boxes come with it (one record)
+            if (COUNT) cnt[0] += 2; // two AABB slab tests (the reference counts one per AABB.hit?, hitable.clj:39)
             float tl, tr;
             bool hl, hr;
             int cl, cr;
@@ -721,6 +722,7 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, int *stack, const BvhRay &r
             else node = RTMI_BVH_EMPTY;
         }
         if (node != RTMI_BVH_EMPTY) { // leaf: one primitive, exact FP64 test
+            if (COUNT) cnt[1] += 1;
             leaf(node);
             best_hi = best();
             if (top != base) { top -= stride; node = *top; }
@@ -730,28 +732,31 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, int *stack, const BvhRay &r
 }
 
 // one loop per record format (a format test inside the loop costs 5 %)
-template <typename Leaf, typename BestHi>
-__device__ inline void bvh_traverse(SceneRef sc, int *stack, const BvhRay &r, Leaf leaf, BestHi best) {
-    if (sc.bvh_node16) bvh_traverse_fmt<true>(sc, stack, r, leaf, best);
-    else bvh_traverse_fmt<false>(sc, stack, r, leaf, best);
+template <bool COUNT = false, typename Leaf, typename BestHi>
+__device__ inline void bvh_traverse(SceneRef sc, int *stack, const BvhRay &r, Leaf leaf, BestHi best, unsigned *cnt = nullptr) {
+    if (sc.bvh_node16) bvh_traverse_fmt<true, COUNT>(sc, stack, r, leaf, best, cnt);
+    else bvh_traverse_fmt<false, COUNT>(sc, stack, r, leaf, best, cnt);
 }
 
 // flat(): the exact flat scan of the same precision, for rays the float boxes cannot bound
-template <typename R, typename Flat>
-__device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, R tmin, R &best_t, int &best_i, Flat flat) {
+// COUNT (diagnostic instantiation, RTMI option "count_traversal"): cnt[0] += AABB slab tests, cnt[1] += exact primitive tests
+template <typename R, bool COUNT = false, typename Flat>
+__device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, R tmin, R &best_t, int &best_i, Flat flat, unsigned *cnt = nullptr) {
     const bool behind_ok = tmin >= R(0);
     const double *exact12 = sc.exact12;
     const BvhRay r = make_bvh_ray<R>(sc, P, a, tmin);
     if (!r.ok) { // rays the float traversal cannot bound take the exact flat scan (all primitives, original order) instead
+        if (COUNT) cnt[1] += (unsigned)sc.n_all;
         flat();
         return;
     }
     // 1. the big primitives (sky dome, ground, ...): exact test, ascending Hitlist index
+    if (COUNT) cnt[1] += (unsigned)sc.n_big;
     for (int k = 0; k < sc.n_big; ++k) exact_prim_test<R>(exact12, sc.big_idx[k], sc.big_idx[k], P, a, tmin, behind_ok, best_t, best_i);
     // 2. the tree
     auto leaf = [&](int code) { exact_prim_test_lane<R>(exact12, code, P, a, tmin, behind_ok, best_t, best_i); };
     auto best = [&]() { return best_t < R(3.0e38) ? float_up((double)best_t) : 3.4028235e38f; };
-    bvh_traverse(sc, stack, r, leaf, best);
+    bvh_traverse<COUNT>(sc, stack, r, leaf, best, cnt);
     // 3. a ray outside the shutter interval: the MovingSphere boxes were built for [t_lo, t_hi], so test every moving sphere exactly
     if (!r.time_ok)
         for (int k = 0; k < sc.n_moving_all; ++k) exact_prim_test_lane<R>(exact12, ~(sc.moving_all[k] | 0x40000000), P, a, tmin, behind_ok, best_t, best_i);

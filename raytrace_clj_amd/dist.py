@@ -54,6 +54,7 @@ class TileRenderer:
         self.ds, self.nx, self.ny, self.rank, self.world = device_scene, nx, ny, rank, world
         self.per = tiles_per_rank(nx, ny, world)
         dev = torch.device("cuda", device_scene.ctx.device)
+        self.dev, self._side, self._ev = dev, None, None
         self.local = torch.zeros((self.per, 64, 3), dtype=torch.float64, device=dev)
         self.counters = torch.zeros(2, dtype=torch.int64, device=dev)
         if rank == 0:
@@ -61,13 +62,100 @@ class TileRenderer:
             self.rgb8 = torch.zeros((ny, nx, 3), dtype=torch.uint8, device=dev)
 
     def step(self, ns, depth=50, seed=0x5EED0002, precision="f64"):
-        """render local tiles -> gather -> (rank 0) assemble.  Asynchronous on the current stream."""
-        stream = torch.cuda.current_stream().cuda_stream
+        """render local tiles -> gather -> (rank 0) assemble.  Asynchronous, ordered with torch's current stream.
+
+        The C-ABI reads stream handle 0 (NULL) as "the context's own stream", and torch's default stream has handle 0: on
+        the default stream the render would run un-ordered with torch's work (the zero-fill of the buffers above, the
+        gather).  So from the default stream the whole step runs on a side stream that first waits for the current stream
+        and that the current stream then waits for."""
+        cur = torch.cuda.current_stream(self.dev)
+        if cur.cuda_stream != 0:
+            return self._step(cur.cuda_stream, ns, depth, seed, precision)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            self._step(self._side.cuda_stream, ns, depth, seed, precision)
+        cur.wait_stream(self._side)
+
+    def _step(self, stream, ns, depth, seed, precision):
         self.ds.render_tiles_device(self.nx, self.ny, ns, self.rank, self.world, self.local, self.counters, depth, seed, precision, stream)
+        if self.world > 1:
+            if self._ev is None:
+                self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._ev[0].record()
         gathered = gather_tiles(self.local, self.world, self.rank)
+        if self.world > 1:
+            self._ev[1].record()
         if self.rank == 0:
             check(_ffi.lib().rtmi_assemble_device(self.ds.ctx.handle, self.nx, self.ny, self.world, self.per, _ffi.ptr(gathered),
                                                   _ffi.ptr(self.linear), _ffi.ptr(self.rgb8), _ffi.ptr(stream)))
+
+
+    def last_gather_ms(self):
+        """milliseconds the last step's gather took on this rank's stream (the transfer plus the wait for the slowest rank)"""
+        if self._ev is None:
+            return 0.0
+        self._ev[1].synchronize()
+        return self._ev[0].elapsed_time(self._ev[1])
+
+
+class MultiDevice:
+    """ONE host process driving several GPUs through the C-ABI (rtmi_render_multi*): what a one-JVM host of the reference
+    (core.clj:100-108) calls.  devices = HIP device ordinals, one replica (context + cloned scene) each; a device may be
+    listed more than once to rehearse the control flow on a one-GPU host (those replicas are gathered by device copies,
+    distinct devices by ONE ncclGather inside the library)."""
+
+    def __init__(self, flat_scene, devices, timing=False, options=None):
+        self.ctxs, self.scenes = [], []
+        for d in devices:
+            ctx = Context(int(d), timing=timing)
+            for k, v in (options or {}).items():
+                ctx.set_option(k, v)
+            self.ctxs.append(ctx)
+            self.scenes.append(DeviceScene(flat_scene, ctx=ctx) if not self.scenes else self.scenes[0].clone(ctx))
+        import ctypes as C
+        self._arr = (C.c_void_p * len(self.scenes))(*[s.handle for s in self.scenes])
+        self.n = len(self.scenes)
+
+    def set_option(self, name, value):
+        for ctx in self.ctxs:
+            ctx.set_option(name, value)
+
+    def render(self, nx, ny, ns, depth=50, seed=0x5EED0002, precision="f64"):
+        """host buffers: (linear [ny,nx,3] float64, rgb8, counters)"""
+        import numpy as np
+        lin, q, cnt = np.zeros((ny, nx, 3)), np.zeros((ny, nx, 3), np.uint8), np.zeros(2, np.uint64)
+        check(_ffi.lib().rtmi_render_multi(self.n, self._arr, nx, ny, ns, depth, seed, {"f64": 0, "f32": 1}[precision],
+                                           _ffi.ptr(lin), _ffi.ptr(q), _ffi.ptr(cnt)))
+        return lin, q, cnt
+
+    def render_device(self, nx, ny, ns, out_linear, out_rgb8, out_counters, depth=50, seed=0x5EED0002, precision="f64"):
+        """outputs: device pointers / torch tensors on devices[0]; asynchronous on replica 0's context stream"""
+        check(_ffi.lib().rtmi_render_multi_device(self.n, self._arr, nx, ny, ns, depth, seed, {"f64": 0, "f32": 1}[precision],
+                                                  _ffi.ptr(out_linear), _ffi.ptr(out_rgb8), _ffi.ptr(out_counters)))
+
+    def sync(self):
+        """wait for every replica (a multi render is complete when replica 0's stream is; the others finished before the gather)"""
+        for ctx in self.ctxs:
+            torch.cuda.synchronize(ctx.device)
+
+    def last_gather_ms(self):
+        import ctypes as C
+        ms = C.c_double()
+        check(_ffi.lib().rtmi_last_gather_ms(self.ctxs[0].handle, C.byref(ms)))
+        return ms.value
+
+    def last_trace_ms(self):
+        """per replica: (sum of trace-kernel ms, launches) since the last call"""
+        return [ctx.last_trace_ms() for ctx in self.ctxs]
+
+    def close(self):
+        for s in self.scenes:
+            s.close()
+        for c in self.ctxs:
+            c.close()
+        self.scenes, self.ctxs = [], []
 
 
 class FramePipeline:

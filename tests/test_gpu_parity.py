@@ -280,6 +280,7 @@ def test_scan_variants_are_bit_identical(oracle, cover11, cover11_moving):
         f = fl.flatten(sc)
         rays = np.concatenate([random_rays(20000, 8), tangent_rays(f, 60000, 9)])
         ctx = core.Context(0)
+        ctx.set_option("accel", 0)  # the Hitlist scan variants (the library default is the BVH)
         ds = core.DeviceScene(f, ctx=ctx)
         outs = []
         for variant in (0, 1, 2, 3):
@@ -426,39 +427,60 @@ def test_bvh_far_origins_and_out_of_shutter_times(oracle, cover11_moving):
     assert (exp[:, 0] == 1).all() and small.mean() > 0.2  # the far rays really do reach the small (incl. moving) spheres
 
 
-def test_bench_json_schema():
-    """bench.py prints ONE JSON line with the contract's keys (run as the driver runs it, tiny step counts)"""
+def _bench(args, env=None, launcher=None, timeout=900):
     import subprocess, sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=300, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_json_schema():
+    """bench.py prints ONE JSON line with the contract's keys (run as the driver runs it, tiny step counts): the N = 1 line is
+    the north-star configuration C3, one frame in flight, with a roofline object no fraction of which exceeds 1"""
+    d = _bench(["--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["value"] > 100 and "workload" in d["config"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in d["roofline"], k
-    assert d["other_accel"]["accel"] == "flat" and d["other_accel"]["value"] > 100
-    assert d["config"]["frames_in_flight"] == 2 and d["serial"]["value"] > 100 and d["roofline"]["pipelined_launch_ms"] > 0 and d["roofline"]["launch_ms"] > 0
+    assert d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["value"] > 100
+    assert d["config"]["workload"].startswith("C3: 1920x1080x256spp") and d["config"]["spheres"] > 9900 and d["config"]["frames_in_flight"] == 1
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm", "launch_ms", "launches_per_step"):
+        assert k in rf, k
+    assert rf["bound"] == "valu" and 0 < rf["hbm"]["frac"] < 1 and (rf["frac"] is None or 0 < rf["frac"] <= 1)
+    assert rf["launch_ms"] * rf["launches_per_step"] <= d["ms_per_step"] * 1.02, "a kernel cannot take longer than the step it is in"
+    assert d["aabb_tests_per_segment"] > 2 and d["prim_tests_per_segment"] >= 2
+    assert d["pipelined"]["value"] > 100 and d["c2"]["value"] > 100 and d["c4"]["value"] > 100 and d["c2"]["workload"].startswith("C2: 800x400x64spp")
+
+
+def test_bench_other_configs_and_flat():
+    d = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--config", "C2"])
+    assert d["config"]["workload"].startswith("C2:") and d["other_accel"]["accel"] == "flat" and d["other_accel"]["value"] > 100
+    assert d["other_accel"]["roofline"]["hbm"]["frac"] < 1
 
 
 def test_two_rank_control_flow_rehearsal():
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), except that both ranks share this
     box's one GPU and the gather goes through gloo on the host (RTMI_BENCH_REHEARSAL=1): tile dealing, per-rank renders, gather,
     assemble, max-over-ranks timing and the JSON line of the N > 1 path"""
-    import subprocess, sys
+    import sys
     env = dict(os.environ, RTMI_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "C1"],
-                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["ns"] == 8 and d["value"] > 0 and "cpu_baseline" not in d
+    d = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "C1"], env=env,
+               launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["ns"] == 4 and d["value"] > 0 and "cpu_baseline" not in d and d["rehearsal"]
     assert abs(d["config"]["segments_per_sample"] - 2.5) < 0.6  # both ranks' segment counters were summed
+    assert d["gather_ms"] >= 0
+
+
+def test_bench_gpus_n_in_one_process():
+    """`python bench.py --gpus 2` exactly as the driver runs the N = 1 case (no launcher): the in-library multi-device entry
+    (rtmi_render_multi_device).  On a one-GPU box the two replicas share the device and the line says so."""
+    import torch
+    d = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "C1"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["launch_form"].startswith("one host process")
+    assert d.get("rehearsal", False) == (torch.cuda.device_count() < 2)
+    assert abs(d["config"]["segments_per_sample"] - 2.5) < 0.6 and d["gather_ms"] >= 0
 
 
 def test_frame_pipeline_renders_the_same_frames():
@@ -485,6 +507,7 @@ def test_bvh_full_size_image_identical():
     sc = r.scene.make_random_scene(nx, ny, 11, True)
     ctx = core.Context(0)
     ds = core.DeviceScene(sc, ctx=ctx)
+    ctx.set_option("accel", 0)
     flat = ds.render(nx, ny, ns)
     ctx.set_option("accel", 1)
     bvh = ds.render(nx, ny, ns)
@@ -699,12 +722,12 @@ def test_media_match_oracle(oracle):
         keys = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
         cam = oracle.probe_camera(f, rng.random((n, 2)), keys)
         ctr0 = int(cam[:, 7].max())
-        ergb, enseg, elog, _ = oracle.probe_paths(f, cam[:, :7], keys, depth=50, ctr0=ctr0, max_seg=6)
+        ergb, enseg, elog, enlog = oracle.probe_paths(f, cam[:, :7], keys, depth=50, ctr0=ctr0, max_seg=6)
         ctx = core.Context(0)
         ds = core.DeviceScene(f, ctx=ctx)
         for accel in (1, 0):
             ctx.set_option("accel", accel)
-            rgb, nseg, log, _ = ds.probe_paths(cam[:, :7], keys, depth=50, ctr0=ctr0, max_seg=6)
+            rgb, nseg, log, nlog = ds.probe_paths(cam[:, :7], keys, depth=50, ctr0=ctr0, max_seg=6)
             same = nseg == enseg
             assert same.mean() > 0.999, (name, accel)
             assert np.array_equal(log[same][:, :, 0], elog[same][:, :, 0]) and np.allclose(log[same], elog[same], rtol=1e-9, atol=1e-9), (name, accel)
@@ -713,7 +736,12 @@ def test_media_match_oracle(oracle):
             assert abs(int(cnt[0]) - int(exp_cnt[0])) <= 2 + 1e-5 * int(exp_cnt[0]) and rms(lin, exp_lin) <= RMS_TOL, (name, accel, rms(lin, exp_lin))
         ds.close(); ctx.close()
         if name == "final":
-            assert (elog[:, :, 0] == np.flatnonzero(f.prim_kind[:f.n_prims] == 7)[0]).any() or True
+            media = np.flatnonzero((f.prim_kind[:f.n_prims] & 15) == 7)
+            logged = np.arange(6)[None, :] < nlog[:, None]  # unlogged records are zero-filled: look at real segments only
+            elogged = np.arange(6)[None, :] < enlog[:, None]
+            hit_dev, hit_orc = np.isin(log[:, :, 0], media) & logged, np.isin(elog[:, :, 0], media) & elogged
+            assert hit_dev.sum() > 10 and hit_orc.sum() > 10, "ConstantMedium primitives are actually hit (device and oracle logs)"
+            assert np.array_equal(hit_dev[same], hit_orc[same])
 
 
 def test_f3_cornell_golden_fixture():
@@ -752,12 +780,15 @@ def test_cull_handles_degenerate_rays():
                      ray7(vec3(0, 0, -5e18), vec3(0, 0, 1)), ray7(vec3(-1e21, 0, 0), vec3(1, 0, 0)), ray7(vec3(0, 0, -5), vec3(np.nan, 0, 1)),
                      ray7(vec3(np.inf, 0, -5), vec3(0, 0, 1))])
     res = {}
+    ds3.ctx.set_option("accel", 0)
     for variant in (0, 3):
         ds3.ctx.set_option("scan_variant", variant)
         res[variant] = ds3.probe_hit(rays, 0.0, 1e300)
     ds3.ctx.set_option("scan_variant", 3)
+    ds3.ctx.set_option("accel", 1)  # the default: these rays take the BVH path's exact-scan fallback
+    res["bvh"] = ds3.probe_hit(rays, 0.0, 1e300)
     ds3.close()
-    assert np.array_equal(res[0], res[3], equal_nan=True)
+    assert np.array_equal(res[0], res[3], equal_nan=True) and np.array_equal(res[0], res["bvh"], equal_nan=True)
     assert list(res[0][:5, 0]) == [1, 1, 0, 1, 1]
 
 
@@ -882,9 +913,15 @@ def test_full_size_properties():
     multi_pass, _, cnt3 = ds.render(nx, ny, ns)
     ctx.set_option("workspace_bytes", 8 << 30)
     assert np.array_equal(base, multi_pass) and np.array_equal(cnt, cnt3), "sample-pass split must not change the image"
+    ctx.set_option("accel", 0)  # the Hitlist scan: scalar-cache + cull (3), then the LDS literal form (0) cut into LDS tiles
+    flat3, _, cnt5 = ds.render(nx, ny, ns)
+    assert np.array_equal(base, flat3) and np.array_equal(cnt, cnt5), "the Hitlist scan and the BVH give the same image"
+    ctx.set_option("scan_variant", 0)
     ctx.set_option("lds_tile_bytes", 4096)  # 128 spheres per LDS tile -> multi-tile scan with barriers
     tiled, _, cnt4 = ds.render(nx, ny, ns)
     ctx.set_option("lds_tile_bytes", 64 * 1024 - 64)
+    ctx.set_option("scan_variant", 3)
+    ctx.set_option("accel", 1)
     assert np.array_equal(base, tiled) and np.array_equal(cnt, cnt4), "LDS sphere tiling must not change the image"
     ctx.set_option("blocks_per_cu", 1)
     geo, _, _ = ds.render(nx, ny, ns)
@@ -916,10 +953,11 @@ def test_full_size_spot_checks_against_oracle(oracle):
     f = fl.flatten(sc)
     ds = core.DeviceScene(f)
     for region in [(392, 196, 408, 204), (0, 0, 16, 8), (600, 300, 616, 308)]:
-        lin, q, _ = ds.render(nx, ny, ns, region=region)
-        exp, eq, _ = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, region=region, nthreads=16)
+        lin, q, cnt = ds.render(nx, ny, ns, region=region)
+        exp, eq, ecnt = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, region=region, nthreads=16)
         assert rms(lin, exp) <= RMS_TOL and rms(lin, exp) < 1e-13
         assert np.abs(q.astype(int) - eq.astype(int)).max() <= 1
+        assert np.array_equal(cnt, ecnt), "both counters describe exactly the region"
     ds.close()
 
 
@@ -931,10 +969,10 @@ def test_config3_scene_10k_spheres_spot_check(oracle):
     assert f.n_prims > 9900
     ds = core.DeviceScene(f)
     region = (952, 620, 968, 628)
-    lin, q, _ = ds.render(nx, ny, ns, region=region)  # the host entry renders the whole frame, then crops
+    lin, q, cnt = ds.render(nx, ny, ns, region=region)  # only the two 8x8 tiles under the region are rendered
     ds.close()
-    exp, eq, _ = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, region=region, nthreads=16)
-    assert rms(lin, exp) <= RMS_TOL and rms(lin, exp) < 1e-13
+    exp, eq, ecnt = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, region=region, nthreads=16)
+    assert rms(lin, exp) <= RMS_TOL and rms(lin, exp) < 1e-13 and np.array_equal(cnt, ecnt)
 
 
 def test_dielectric_heavy_scene(oracle):
