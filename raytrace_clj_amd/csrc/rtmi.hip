@@ -82,6 +82,9 @@ struct TraceParams {
 #ifndef RTMI_QUEUE_BLOCK
 #define RTMI_QUEUE_BLOCK 256
 #endif
+#ifndef RTMI_STASH
+#define RTMI_STASH 1 // camera rays generated 64 at a time at full wave width into a register stash (0: per trip, for the dead lanes only)
+#endif
 constexpr unsigned kQueueBlock = RTMI_QUEUE_BLOCK; // work items a wave claims per queue access: 4 chunks = one tile x 4 consecutive samples
 
 template <typename R> __device__ inline const R *stat4_of(SceneRef sc);
@@ -188,7 +191,6 @@ template <typename R> __device__ inline void start_sample(SceneRef sc, const Tra
     get_ray<R>(sc, u, v, P);
     RTMI_SUBSTAMP(14)
     P.ar = P.ag = P.ab = R(1);
-    P.cr = P.cg = P.cb = R(0);
     P.depth = tp.depth;
 }
 
@@ -210,11 +212,17 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
     unsigned w_cur = 0, w_end = 0; // this wave's claimed range [w_cur, w_end): wave-uniform
     Path<R> P;
     P.ox = P.oy = P.oz = P.dx = P.dy = P.dz = P.time = R(0);
-    P.ar = P.ag = P.ab = P.cr = P.cg = P.cb = R(0);
+    P.ar = P.ag = P.ab = R(0);
     seed_stream(P, 0ull, 0u); P.depth = 0;
     bool alive = false;
     bool exhausted = (total_items == 0);
-    size_t out_idx = 0;
+    unsigned out_item = 0; // work item of the lane's path: its colour goes to samples[out_item]
+#if RTMI_STASH
+    R st_ox = R(0), st_oy = R(0), st_oz = R(0), st_dx = R(0), st_dy = R(0), st_dz = R(0), st_time = R(0); // the stash: one generated camera ray per lane
+    u64 st_rs = 0;
+    unsigned st_item = 0xffffffffu;
+    unsigned s_head = 64u; // wave-uniform: entries [s_head, 64) are unclaimed
+#endif
     unsigned nrays = 0;
     unsigned ntrav[2] = {0u, 0u};
     const R tmin = R(0.001), tmax = Real<R>::tmax();
@@ -222,7 +230,61 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
     RTMI_STAMP_DECL
     for (;;) {
         RTMI_STAMP(5) // loop overhead / tail
-        // ---- refill dead lanes: ballot -> popcount prefix -> one LDS atomic per wave -------------------
+        // ---- refill dead lanes ------------------------------------------------------------------------------------------
+#if RTMI_STASH
+        // Camera rays are generated 64 at a time by the WHOLE wave (key, jitter, lens disk loop, get-ray: start_sample at full
+        // width) into a register stash, one entry per lane; dead lanes then pull entries across lanes (ds_bpermute): entry
+        // s_head + (rank among the dead lanes).  Generating per trip for the dead lanes only ran start_sample at ~40 % width
+        // every trip; now it runs at full width every ~2.5 trips.  Which lane traces an item never affects the result.
+        for (;;) { // wave-uniform control flow
+            const u64 dead = __ballot(!alive);
+            if (dead == 0) break;
+            if (s_head == 64u) {
+                if (exhausted) break;
+                if (w_cur == w_end) {
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(tp.queue, kQueueBlock);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= total_items) { exhausted = true; break; }
+                    w_cur = base;
+                    w_end = min(base + kQueueBlock, total_items); // total_items and kQueueBlock are multiples of 64
+                }
+                const unsigned m = w_cur + (unsigned)lane;
+                w_cur += 64u;
+                const unsigned chunk = m >> 6;
+                const int l = (int)(m & 63u);
+                const int tile_local = (int)(chunk / (unsigned)tp.s_count);
+                const int s = tp.s_begin + (int)(chunk - (unsigned)tile_local * (unsigned)tp.s_count);
+                const int gtile = tp.tile_ids[tile_local];
+                const int x = (gtile % tp.tiles_x) * RTMI_TILE + (l & 7);
+                const int y = (gtile / tp.tiles_x) * RTMI_TILE + (l >> 3);
+                st_item = 0xffffffffu; // an item outside the image / region: an empty entry
+                if (x >= tp.rx0 && x < tp.rx1 && y >= tp.ry0 && y < tp.ry1) {
+                    Path<R> Q;
+                    start_sample<R>(sc, tp, x, tp.ny - 1 - y, s, Q); // j = ny-1-y (core.clj:105)
+                    st_ox = Q.ox; st_oy = Q.oy; st_oz = Q.oz; st_dx = Q.dx; st_dy = Q.dy; st_dz = Q.dz; st_time = Q.time; st_rs = Q.rs;
+                    st_item = m;
+                }
+                s_head = 0u;
+            }
+            const unsigned avail = 64u - s_head, nd = (unsigned)__popcll(dead);
+            const unsigned rank = (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
+            const bool take = !alive && rank < avail;
+            const int src = take ? (int)(s_head + rank) : lane;
+            const R f_ox = __shfl(st_ox, src), f_oy = __shfl(st_oy, src), f_oz = __shfl(st_oz, src);
+            const R f_dx = __shfl(st_dx, src), f_dy = __shfl(st_dy, src), f_dz = __shfl(st_dz, src), f_time = __shfl(st_time, src);
+            const u64 f_rs = __shfl(st_rs, src);
+            const unsigned f_item = __shfl(st_item, src);
+            if (take && f_item != 0xffffffffu) {
+                P.ox = f_ox; P.oy = f_oy; P.oz = f_oz; P.dx = f_dx; P.dy = f_dy; P.dz = f_dz; P.time = f_time; P.rs = f_rs;
+                P.ar = P.ag = P.ab = R(1);
+                P.depth = tp.depth;
+                out_item = f_item;
+                alive = true;
+            }
+            s_head += min(nd, avail);
+        }
+#else
         while (!exhausted) { // every lane of the wave takes part: the loop conditions are wave-uniform
             const u64 dead = __ballot(!alive);
             if (dead == 0) break;
@@ -247,12 +309,13 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
                 const int y = (gtile / tp.tiles_x) * RTMI_TILE + (l >> 3);
                 if (x >= tp.rx0 && x < tp.rx1 && y >= tp.ry0 && y < tp.ry1) {
                     start_sample<R>(sc, tp, x, tp.ny - 1 - y, s, P); // j = ny-1-y (core.clj:105)
-                    out_idx = (size_t)m * 3;
+                    out_item = m;
                     alive = true;
                 }
             }
             w_cur += min((unsigned)__popcll(dead), avail);
         }
+#endif
         if (MULTI) { if (!__syncthreads_or(alive ? 1 : 0)) break; }
         else { if (!__any(alive ? 1 : 0)) break; }
         RTMI_STAMP(0) // refill
@@ -263,9 +326,10 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
         RTMI_STAMP(1) // intersection
         if (alive) {
             ++nrays;
-            if (!shade_segment<R, EXT>(sc, P, best_t, best_i, nullptr)) {
-                R *out = reinterpret_cast<R *>(tp.samples) + out_idx;
-                out[0] = P.cr; out[1] = P.cg; out[2] = P.cb;
+            R emit[3];
+            if (!shade_segment<R, EXT>(sc, P, best_t, best_i, nullptr, emit)) {
+                R *out = reinterpret_cast<R *>(tp.samples) + (size_t)out_item * 3;
+                out[0] = emit[0]; out[1] = emit[1]; out[2] = emit[2];
                 alive = false;
             }
         }
@@ -375,7 +439,7 @@ __global__ void sum_counters_kernel(const u64 *gathered, int world, size_t rank_
 // ---- probe kernels (one protocol call per thread; same device functions as trace_kernel) -------------
 template <typename R> __device__ inline void load_ray(const double *q, Path<R> &P) {
     P.ox = (R)q[0]; P.oy = (R)q[1]; P.oz = (R)q[2]; P.dx = (R)q[3]; P.dy = (R)q[4]; P.dz = (R)q[5]; P.time = (R)q[6];
-    P.ar = P.ag = P.ab = R(1); P.cr = P.cg = P.cb = R(0); seed_stream(P, 0ull, 0u); P.depth = 0;
+    P.ar = P.ag = P.ab = R(1); seed_stream(P, 0ull, 0u); P.depth = 0;
 }
 
 template <typename R, int VARIANT, bool EXT = false>
@@ -413,16 +477,19 @@ __global__ void __launch_bounds__(kBlock) probe_paths_kernel(ScenePtr scp, int p
     SegLog lg = {log ? log + (size_t)(alive ? k : 0) * max_seg * RTMI_SEG_REC : nullptr, max_seg, 0};
     u64 nseg = 0;
     const R tmin = R(0.001), tmax = Real<R>::tmax();
+    R rgb[3] = {R(0), R(0), R(0)};
     while (__syncthreads_or(alive ? 1 : 0)) {
         R best_t; int best_i;
         intersect_world<R, true, VARIANT, EXT>(sc, lds, prims_per_tile, n_ptiles, P, alive, tmin, tmax, best_t, best_i);
         if (alive) {
             ++nseg;
-            alive = shade_segment<R, EXT>(sc, P, best_t, best_i, log ? &lg : nullptr);
+            R emit[3];
+            alive = shade_segment<R, EXT>(sc, P, best_t, best_i, log ? &lg : nullptr, emit);
+            if (!alive) { rgb[0] = emit[0]; rgb[1] = emit[1]; rgb[2] = emit[2]; }
         }
     }
     if (k < n) {
-        out_rgb[3 * k] = P.cr; out_rgb[3 * k + 1] = P.cg; out_rgb[3 * k + 2] = P.cb;
+        out_rgb[3 * k] = rgb[0]; out_rgb[3 * k + 1] = rgb[1]; out_rgb[3 * k + 2] = rgb[2];
         if (out_nseg) out_nseg[k] = nseg;
         if (out_nlog) out_nlog[k] = lg.n;
     }
@@ -462,8 +529,8 @@ __global__ void probe_scatter_kernel(ScenePtr scp, int mat, int n, const double 
     HitRec<R> h;
     h.t = R(0); h.px = (R)hq[0]; h.py = (R)hq[1]; h.pz = (R)hq[2]; h.nx = (R)hq[3]; h.ny = (R)hq[4]; h.nz = (R)hq[5];
     h.u = (R)hq[6]; h.v = (R)hq[7]; h.orig = -1; h.kind = RTMI_PRIM_SPHERE; h.mat = mat;
-    R att[3] = {R(0), R(0), R(0)};
-    const bool scat = scatter_emit<R, F4>(sc, P, h, att);
+    R att[3] = {R(0), R(0), R(0)}, emit[3];
+    const bool scat = scatter_emit<R, F4>(sc, P, h, att, emit);
     double *o = out + (size_t)k * 9;
     o[0] = scat ? 1.0 : 0.0;
     o[1] = scat ? P.dx : 0; o[2] = scat ? P.dy : 0; o[3] = scat ? P.dz : 0;

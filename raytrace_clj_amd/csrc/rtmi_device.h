@@ -140,7 +140,8 @@ __device__ inline float pow5(float x) { const double d = (double)x, d2 = d * d; 
 template <typename R> struct Path {
     R ox, oy, oz, dx, dy, dz, time; // ray map {:origin :direction :time}, util.clj:13-16
     R ar, ag, ab;                   // atten
-    R cr, cg, cb;                   // accum
+    // accum is not carried: every Shader whose emitted is non-zero (DiffuseLight, shader.clj:114-119) returns nil from scatter,
+    // so accum is still (0 0 0) when the path's last segment adds atten * emitted (core.clj:37-39) -- see scatter_emit's `emit`
     u64 key;
     u64 rs;       // running stream state = key + GOLD * ctr  (bits(key, d) = mix64(key + GOLD*(d+1)): one add per draw)
     unsigned ctr; // draws consumed (reported by the probes)
@@ -1092,8 +1093,9 @@ template <> __device__ inline void resolve_any<double, true>(SceneRef sc, const 
 
 // Shader.scatter + Shader.emitted for the hit record, and the atten/accum update of core.clj:27-39.
 // Returns true when the path continues (the `recur` of core.clj:30) with P holding the scattered ray.
-// `att` (optional) receives the attenuation of a successful scatter.
-template <typename R, bool F4 = false> __device__ inline bool scatter_emit(SceneRef sc, Path<R> &P, const HitRec<R> &h, R *att) {
+// `att` (optional) receives the attenuation of a successful scatter.  `emit` receives accum + atten * emitted of a path that
+// ends here (core.clj:37-39) with accum = (0 0 0): only a path's LAST segment can emit (the emitting Shader never scatters).
+template <typename R, bool F4 = false> __device__ inline bool scatter_emit(SceneRef sc, Path<R> &P, const HitRec<R> &h, R *att, R *emit) {
     // The material switch is laid out in PHASES shared by the materials that need them (one rejection-sampler loop,
     // one |d| normalisation, one texture evaluation per trip) instead of one inlined copy per material: the lanes of a
     // wave hold different materials, so every copy would be executed serially.  Per lane the operations and the draw
@@ -1109,6 +1111,7 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
     const bool is_lamb = live && mk == RTMI_MAT_LAMBERTIAN, is_metal = live && mk == RTMI_MAT_METAL, is_diel = live && mk == RTMI_MAT_DIELECTRIC;
     const bool is_iso = F4 && live && mk == RTMI_MAT_ISOTROPIC; // shader.clj:129-138, the phase function of ConstantMedium
     bool scat = false;
+    emit[0] = emit[1] = emit[2] = R(0);
     R sdx = R(0), sdy = R(0), sdz = R(0); // scattered direction
     R atr = R(1), atg = R(1), atb = R(1);  // attenuation
 
@@ -1175,7 +1178,7 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
             const bool neg = sx * sy * sz < 0;
             tr = neg ? (R)m1.y : (R)m3.y; tg = neg ? (R)m2.x : (R)m4.x; tb = neg ? (R)m2.y : (R)m4.y;
         } else tex_sample<R, F4>(sc, mtex, h.u, h.v, px, py, pz, tr, tg, tb);
-        if (is_light) { P.cr = P.cr + P.ar * tr; P.cg = P.cg + P.ag * tg; P.cb = P.cb + P.ab * tb; } // core.clj:37-39
+        if (is_light) { emit[0] = R(0) + P.ar * tr; emit[1] = R(0) + P.ag * tg; emit[2] = R(0) + P.ab * tb; } // core.clj:37-39: (add accum (mul atten emitted))
         else { atr = tr; atg = tg; atb = tb; }
     }
     RTMI_SUBSTAMP(12)
@@ -1190,13 +1193,14 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
 
 // One iteration of `color`'s loop after hit? has returned (core.clj:25-41).
 template <typename R, bool EXT = false>
-__device__ inline bool shade_segment(SceneRef sc, Path<R> &P, R t, int orig, SegLog *lg) {
+__device__ inline bool shade_segment(SceneRef sc, Path<R> &P, R t, int orig, SegLog *lg, R *emit) {
+    emit[0] = emit[1] = emit[2] = R(0);
     if (orig < 0) return false; // miss: (color) returns accum, core.clj:40-41
     HitRec<R> h;
     RTMI_SUBSTAMP(-1)
     resolve_any<R, EXT>(sc, P, t, orig, h, false);
     RTMI_SUBSTAMP(8)
-    const bool scat = scatter_emit<R, EXT>(sc, P, h, nullptr);
+    const bool scat = scatter_emit<R, EXT>(sc, P, h, nullptr, emit);
     if (lg && lg->n < lg->max_seg) {
         double *q = lg->rec + (size_t)lg->n * RTMI_SEG_REC;
         q[0] = h.orig; q[1] = h.t; q[2] = h.px; q[3] = h.py; q[4] = h.pz; q[5] = h.nx; q[6] = h.ny; q[7] = h.nz;
