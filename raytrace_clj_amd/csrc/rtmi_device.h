@@ -553,7 +553,7 @@ __device__ inline void scan_all_cull(SceneRef sc, const Path<double> &P, double 
 // ---- RTMI_ACCEL_BVH: per-lane BVH traversal with conservative float boxes, exact FP64 leaves -------------------------
 // Closest hit is order independent: candidate(prim) = first root if > t-min else second root (hitable.clj:192-207 with the
 // running t-max of hitable.clj:20 only ever rejecting non-minimal candidates); ties -> lowest Hitlist index (first wins).
-#define RTMI_BVH_EMPTY 0x7fffffff
+#define RTMI_BVH_EMPTY ((int)0x80000000) // no child / traversal done; negative like the leaf codes, so "inner node" is one sign test (a leaf code ~(idx | moving << 30) never equals it)
 #ifndef RTMI_BVH_STACK
 #define RTMI_BVH_STACK 32
 #endif
@@ -601,8 +601,9 @@ __device__ inline void exact_prim_test_lane(const double *exact12, int code, con
 // the scene bound (far: e.g. after scattering in a scene-sized ConstantMedium) moves every plane outward by its own
 // e = 2^-20 |o|_inf instead (|oc| <= 2 sqrt(3) |o|_inf there, plus one more rounding): the slack e |inv| is folded into the additive
 // constant per plane (c_lo for the planes x = lo, c_hi for x = hi; which of the two is the entry plane is the sign of inv).
-// The remaining relative error on t (<= 4u with the rounding of inv) is absorbed by lowering the entry distance and raising the
-// exit distance by 8u before comparing.
+// The remaining relative error on t (<= 4u with the rounding of inv) moves the computed crossing of a plane along its own axis by
+// <= 4u |t d_k| = 4u |plane - o_k| <= 4u (cbound + |o|_inf): every ray moves every plane outward by 8u (cbound + |o|_inf) itself
+// (folded into the same per-plane constants, so a node visit pays nothing for it).
 // Both children of a node are tested together; the x/y planes go through packed FMAs (v_pk_fma_f32), z as (lo, hi) pairs.
 typedef float v2f __attribute__((ext_vector_type(2)));
 struct BvhRay { v2f ixy, izz, clxy, chxy, czz; float tmin_lo; bool ok, far, time_ok; };
@@ -611,20 +612,14 @@ struct BvhRay { v2f ixy, izz, clxy, chxy, czz; float tmin_lo; bool ok, far, time
 // picks it when rounding to half grows the boxes' total area by less than a quarter (coordinates small against object sizes).
 struct __attribute__((aligned(16))) Node16 { _Float16 p[12]; int cl, cr; }; // l: lo.x hi.x lo.y hi.y lo.z hi.z, r: the same, left, right
 __device__ inline bool slab_hit6(float ax, float bx, float ay, float by, float az, float bz, const float tmin_lo, const float best_hi, float &tnear) {
-    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    const float ku = 8.0f * 5.9604645e-08f;
-    tn = fmaf(-ku, fabsf(tn), tn);
-    tf = fmaf(ku, fabsf(tf), tf);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     tnear = tn;
     return (tn <= tf) && (tf >= tmin_lo) && (tn <= best_hi);
 }
 __device__ inline bool slab_hit(const v2f a, const v2f b, const v2f z, const float tmin_lo, const float best_hi, float &tnear) {
-    float tn = fmaxf(fmaxf(fminf(a.x, b.x), fminf(a.y, b.y)), fminf(z.x, z.y));
-    float tf = fminf(fminf(fmaxf(a.x, b.x), fmaxf(a.y, b.y)), fmaxf(z.x, z.y));
-    const float ku = 8.0f * 5.9604645e-08f;
-    tn = fmaf(-ku, fabsf(tn), tn);
-    tf = fmaf(ku, fabsf(tf), tf);
+    const float tn = fmaxf(fmaxf(fminf(a.x, b.x), fminf(a.y, b.y)), fminf(z.x, z.y));
+    const float tf = fminf(fminf(fmaxf(a.x, b.x), fmaxf(a.y, b.y)), fmaxf(z.x, z.y));
     tnear = tn;
     return (tn <= tf) && (tf >= tmin_lo) && (tn <= best_hi);
 }
@@ -656,8 +651,9 @@ __device__ inline BvhRay make_bvh_ray(SceneRef sc, const Path<R> &P, R a, R tmin
     // (u = 2^-24), so the test can report a hit for a line that passes the centre at p with p^2 <= r^2 + 40u(|oc|^2 + r^2), i.e.
     // up to 1.55e-3 sqrt(|oc|^2 + r^2) outside the sphere; with |oc| <= sqrt(3)(|o|_inf + cbound) and r <= cbound (cbound = the
     // largest coordinate of any box in the tree) that is < 3.1e-3 (|o|_inf + cbound): every plane moves out by 4e-3 of that.
-    const float e = sizeof(R) == sizeof(float) ? fmaxf(omax, sc.bvh_obound) * (1.0001f / 1048576.0f) + 4.0e-3f * (omax + sc.bvh_cbound)
-                                               : (r.far ? omax * (1.0001f / 1048576.0f) : 0.0f);
+    const float e = (sizeof(R) == sizeof(float) ? fmaxf(omax, sc.bvh_obound) * (1.0001f / 1048576.0f) + 4.0e-3f * (omax + sc.bvh_cbound)
+                                                : (r.far ? omax * (1.0001f / 1048576.0f) : 0.0f)) +
+                    (8.0f * 5.9604645e-08f * 1.0001f) * (omax + sc.bvh_cbound); // the relative error of t as a plane shift (see slab_hit)
     // signed slack: the plane x = lo is the entry plane when inv >= 0 (entry distances are lowered, exit distances raised)
     const float ex = e * ix, ey = e * iy, ez = e * iz; // = e |inv| * sign(inv)
     r.ixy = v2f{ix, iy}; r.izz = v2f{iz, iz};
@@ -681,15 +677,18 @@ __device__ inline unsigned long long stamp_now() {
 #endif
 template <bool NODE16, bool COUNT, typename Leaf, typename BestHi>
 __device__ inline void bvh_traverse_fmt(SceneRef sc, int *stack, const BvhRay &r, Leaf leaf, BestHi best, unsigned *cnt) {
-    int node = sc.bvh_root; // inner node: byte offset of its record (>= 0); leaf: ~(primitive | moving << 30) (< 0)
+    int node = sc.bvh_root; // inner node: byte offset of its record (>= 0); leaf: ~(primitive | moving << 30) (< 0); RTMI_BVH_EMPTY: done
     if (node == RTMI_BVH_EMPTY) return;
     const int stride = blockDim.x;
-    int *const base = stack + threadIdx.x;
-    int *top = base; // next free slot of this thread's column
+    // The newest stack entry lives in a register (tos), the older ones in this thread's LDS column; the bottom entry is a sentinel
+    // (RTMI_BVH_EMPTY, the initial tos), so popping needs no emptiness test and the LDS read of a pop is only needed by the NEXT
+    // pop or push: its latency is off the critical path.  (The tree's depth is < RTMI_BVH_STACK - 1 by construction.)
+    int *top = stack + stride + threadIdx.x; // next free slot of this thread's column (level 0 is only ever READ, by the pop of the sentinel)
+    int tos = RTMI_BVH_EMPTY;
     const char *nodes = reinterpret_cast<const char *>(sc.bvh_nodes);
     float best_hi = best();
     while (node != RTMI_BVH_EMPTY) {
-        while (node >= 0 && node != RTMI_BVH_EMPTY) { // inner node: both child boxes come with it (one record)
+        while (node >= 0) { // inner node: both child boxes come with it (one record)
             if (COUNT) cnt[0] += 2; // two AABB slab tests (the reference counts one per AABB.hit?, hitable.clj:39)
             float tl, tr;
             bool hl, hr;
@@ -712,22 +711,21 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, int *stack, const BvhRay &r
                               __builtin_elementwise_fma(v2f{n2.z, n2.w}, r.izz, r.czz), r.tmin_lo, best_hi, tr);
                 cl = __float_as_int(n3.x); cr = __float_as_int(n3.y);
             }
-            if (hl && hr) {
+            if (hl && hr) { // push the far child, descend into the near one
                 const bool left_first = tl <= tr;
-                *top = left_first ? cr : cl;
+                *top = tos;
                 top += stride;
+                tos = left_first ? cr : cl;
                 node = left_first ? cl : cr;
             } else if (hl) node = cl;
             else if (hr) node = cr;
-            else if (top != base) { top -= stride; node = *top; }
-            else node = RTMI_BVH_EMPTY;
+            else { node = tos; top -= stride; tos = *top; } // pop (the sentinel ends the traversal)
         }
         if (node != RTMI_BVH_EMPTY) { // leaf: one primitive, exact FP64 test
             if (COUNT) cnt[1] += 1;
             leaf(node);
             best_hi = best();
-            if (top != base) { top -= stride; node = *top; }
-            else node = RTMI_BVH_EMPTY;
+            node = tos; top -= stride; tos = *top;
         }
     }
 }
