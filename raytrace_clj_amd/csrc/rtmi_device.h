@@ -105,7 +105,12 @@ __device__ inline void substamp(int k) {
 #endif
 template <typename R> struct Real;
 template <> struct Real<double> {
-    __device__ static inline double uniform(u64 z) { return (double)(z >> 11) * (1.0 / 9007199254740992.0); }
+    // k = z >> 11 (53 bits) as a double: hi * 2^32 + lo in one fma (exact: k needs 53 bits), then k * 2^-53 (exact)
+    __device__ static inline double k53(u64 z) { const u64 k = z >> 11; return ::fma((double)(unsigned)(k >> 32), 4294967296.0, (double)(unsigned)k); }
+    __device__ static inline double uniform(u64 z) { return k53(z) * (1.0 / 9007199254740992.0); }
+    // 2 * uniform - 1 (util.clj:35-36, 46-48) in one fma: k * 2^-52 - 1 = (k - 2^52) * 2^-52 is a 53-bit integer times a power of two,
+    // i.e. exact, like the two exact operations (* 2.0 u) and (- ... 1.0) it replaces
+    __device__ static inline double symmetric(u64 z) { return ::fma(k53(z), 1.0 / 4503599627370496.0, -1.0); }
     __device__ static inline double tmax() { return 3.4028234663852886e38; } // Float/MAX_VALUE, core.clj:25
     __device__ static inline double pi() { return 3.141592653589793; }
     __device__ static inline double sqrt_(double x) { return ::sqrt(x); }
@@ -116,6 +121,7 @@ template <> struct Real<double> {
 };
 template <> struct Real<float> {
     __device__ static inline float uniform(u64 z) { return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f); }
+    __device__ static inline float symmetric(u64 z) { return 2.0f * uniform(z) - 1.0f; } // both operations exact (24-bit k)
     __device__ static inline float tmax() { return 3.4028234663852886e38f; }
     __device__ static inline float pi() { return 3.141592653589793f; }
     __device__ static inline float sqrt_(float x) { return ::sqrtf(x); }
@@ -155,22 +161,28 @@ template <typename R> __device__ inline R next_uniform(Path<R> &P) {
     return Real<R>::uniform(mix64(P.rs));
 }
 
+template <typename R> __device__ inline R next_symmetric(Path<R> &P) { // (dec (* 2.0 (rand))) of the rejection samplers
+    P.rs += RTMI_GOLD;
+    P.ctr++;
+    return Real<R>::symmetric(mix64(P.rs));
+}
+
 template <typename R> __device__ inline R dot3(R ax, R ay, R az, R bx, R by, R bz) { return (ax * bx + ay * by) + az * bz; }
 
 // util.clj:43-52 rand-in-unit-sphere (x, y, z drawn in that order; retry while p.p >= 1.0)
 template <typename R> __device__ inline void rand_in_unit_sphere(Path<R> &P, R &x, R &y, R &z) {
     for (;;) {
-        x = R(2.0) * next_uniform(P) - R(1.0);
-        y = R(2.0) * next_uniform(P) - R(1.0);
-        z = R(2.0) * next_uniform(P) - R(1.0);
+        x = next_symmetric(P);
+        y = next_symmetric(P);
+        z = next_symmetric(P);
         if (!(dot3(x, y, z, x, y, z) >= R(1.0))) return;
     }
 }
 // util.clj:32-41 rand-in-unit-disk
 template <typename R> __device__ inline void rand_in_unit_disk(Path<R> &P, R &x, R &y) {
     for (;;) {
-        x = R(2.0) * next_uniform(P) - R(1.0);
-        y = R(2.0) * next_uniform(P) - R(1.0);
+        x = next_symmetric(P);
+        y = next_symmetric(P);
         if (!(dot3(x, y, R(0), x, y, R(0)) >= R(1.0))) return;
     }
 }
@@ -606,22 +618,26 @@ __device__ inline void exact_prim_test_lane(const double *exact12, int code, con
 // (folded into the same per-plane constants, so a node visit pays nothing for it).
 // Both children of a node are tested together; the x/y planes go through packed FMAs (v_pk_fma_f32), z as (lo, hi) pairs.
 typedef float v2f __attribute__((ext_vector_type(2)));
-struct BvhRay { v2f ixy, izz, clxy, chxy, czz; float tmin_lo; bool ok, far, time_ok; };
+struct BvhRay { v2f ixy, izz, clxy, chxy, czz; float tmin_lo; bool ok, far, time_ok;
+                // Node16 path: which half of a {lo, hi} pair is the ENTRY plane is the sign of the direction, so the pair is rotated
+                // by sh (0 or 16 bits) and entry / exit distances come out of the fma directly -- no min / max per axis
+                unsigned shx, shy, shz; float cex, cey, cez, cxx, cxy, cxz; };
 // 32-byte node format (DevScene::bvh_node16): the planes as IEEE half, rounded outward on the host, consumed by v_fma_mix_f32
 // without a conversion instruction: half the bytes per step through the texture-address / L1 path (C2 -3 %, C3 -6 %).  The host
 // picks it when rounding to half grows the boxes' total area by less than a quarter (coordinates small against object sizes).
 struct __attribute__((aligned(16))) Node16 { _Float16 p[12]; int cl, cr; }; // l: lo.x hi.x lo.y hi.y lo.z hi.z, r: the same, left, right
+// hit  <=>  max(entry distances, t-min) <= min(exit distances, best t so far)
 __device__ inline bool slab_hit6(float ax, float bx, float ay, float by, float az, float bz, const float tmin_lo, const float best_hi, float &tnear) {
-    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin_lo));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_hi));
     tnear = tn;
-    return (tn <= tf) && (tf >= tmin_lo) && (tn <= best_hi);
+    return tn <= tf;
 }
 __device__ inline bool slab_hit(const v2f a, const v2f b, const v2f z, const float tmin_lo, const float best_hi, float &tnear) {
-    const float tn = fmaxf(fmaxf(fminf(a.x, b.x), fminf(a.y, b.y)), fminf(z.x, z.y));
-    const float tf = fminf(fminf(fmaxf(a.x, b.x), fmaxf(a.y, b.y)), fmaxf(z.x, z.y));
+    const float tn = fmaxf(fmaxf(fminf(a.x, b.x), fminf(a.y, b.y)), fmaxf(fminf(z.x, z.y), tmin_lo));
+    const float tf = fminf(fminf(fmaxf(a.x, b.x), fmaxf(a.y, b.y)), fminf(fmaxf(z.x, z.y), best_hi));
     tnear = tn;
-    return (tn <= tf) && (tf >= tmin_lo) && (tn <= best_hi);
+    return tn <= tf;
 }
 
 __device__ inline float float_up(double x) { // smallest float >= x (x finite, |x| < FLT_MAX)
@@ -643,7 +659,8 @@ __device__ inline BvhRay make_bvh_ray(SceneRef sc, const Path<R> &P, R a, R tmin
            (a > R(1e-30)) && (a < R(1e30)) && (tmin > R(-1e30)) && (tmin < R(1e30)) && (sc.bvh_obound >= 0.0f);
     r.far = omax > sc.bvh_obound;
     r.time_ok = (P.time >= sc.cull_t_lo) && (P.time <= sc.cull_t_hi); // else the MovingSphere boxes do not bound this ray's spheres
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    // v_rcp_f32: <= 1 ulp = 2u of relative error; with the rounding of d (u) and of the fma (u) the "<= 4u" of slab_hit's budget
+    const float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
     const float cx = -ox * ix, cy = -oy * iy, cz = -oz * iz;
     // RTMI_F32: the boxes must also catch what the FLOAT sphere test calls a hit.  (a) The float spheres (rounded centres, float
     // r*r, float lerp) may stick out of the boxes built from the FP64 geometry by a few 2^-24 |c|: 2^-20 of the larger of |o|
@@ -659,7 +676,10 @@ __device__ inline BvhRay make_bvh_ray(SceneRef sc, const Path<R> &P, R a, R tmin
     r.ixy = v2f{ix, iy}; r.izz = v2f{iz, iz};
     r.clxy = v2f{cx - ex, cy - ey}; r.chxy = v2f{cx + ex, cy + ey};
     r.czz = v2f{cz - ez, cz + ez};
-    r.tmin_lo = r.ok ? -float_up(-(double)tmin) : 0.0f;
+    r.shx = ix < 0.0f ? 16u : 0u; r.shy = iy < 0.0f ? 16u : 0u; r.shz = iz < 0.0f ? 16u : 0u;
+    r.cex = cx - fabsf(ex); r.cey = cy - fabsf(ey); r.cez = cz - fabsf(ez); // entry planes move towards the origin of the ray,
+    r.cxx = cx + fabsf(ex); r.cxy = cy + fabsf(ey); r.cxz = cz + fabsf(ez); // exit planes away from it
+    r.tmin_lo = -float_up(-(double)tmin); // (a compile-time constant in the render kernel: t-min = 0.001, core.clj:25)
     return r;
 }
 
@@ -694,14 +714,19 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, int *stack, const BvhRay &r
             bool hl, hr;
             int cl, cr;
             if (NODE16) {
-                const Node16 nd = *reinterpret_cast<const Node16 *>(nodes + (unsigned)node);
-                hl = slab_hit6(fmaf((float)nd.p[0], r.ixy.x, r.clxy.x), fmaf((float)nd.p[1], r.ixy.x, r.chxy.x), fmaf((float)nd.p[2], r.ixy.y, r.clxy.y),
-                               fmaf((float)nd.p[3], r.ixy.y, r.chxy.y), fmaf((float)nd.p[4], r.izz.x, r.czz.x), fmaf((float)nd.p[5], r.izz.x, r.czz.y),
-                               r.tmin_lo, best_hi, tl);
-                hr = slab_hit6(fmaf((float)nd.p[6], r.ixy.x, r.clxy.x), fmaf((float)nd.p[7], r.ixy.x, r.chxy.x), fmaf((float)nd.p[8], r.ixy.y, r.clxy.y),
-                               fmaf((float)nd.p[9], r.ixy.y, r.chxy.y), fmaf((float)nd.p[10], r.izz.x, r.czz.x), fmaf((float)nd.p[11], r.izz.x, r.czz.y),
-                               r.tmin_lo, best_hi, tr);
-                cl = nd.cl; cr = nd.cr;
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const uint4 *q = reinterpret_cast<const uint4 *>(nodes + (unsigned)node);
+                const uint4 n0 = q[0], n1 = q[1]; // l.x l.y l.z r.x | r.y r.z left right   (each plane pair = {lo, hi} halves)
+                const h2 lx = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(n0.x, n0.x, r.shx)), ly = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(n0.y, n0.y, r.shy)),
+                         lz = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(n0.z, n0.z, r.shz)), rx = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(n0.w, n0.w, r.shx)),
+                         ry = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(n1.x, n1.x, r.shy)), rz = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(n1.y, n1.y, r.shz));
+                // hit  <=>  max(entry distances, t-min) <= min(exit distances, best t so far)
+                tl = fmaxf(fmaxf(fmaf((float)lx.x, r.ixy.x, r.cex), fmaf((float)ly.x, r.ixy.y, r.cey)), fmaxf(fmaf((float)lz.x, r.izz.x, r.cez), r.tmin_lo));
+                tr = fmaxf(fmaxf(fmaf((float)rx.x, r.ixy.x, r.cex), fmaf((float)ry.x, r.ixy.y, r.cey)), fmaxf(fmaf((float)rz.x, r.izz.x, r.cez), r.tmin_lo));
+                const float fl = fminf(fminf(fmaf((float)lx.y, r.ixy.x, r.cxx), fmaf((float)ly.y, r.ixy.y, r.cxy)), fminf(fmaf((float)lz.y, r.izz.x, r.cxz), best_hi));
+                const float fr = fminf(fminf(fmaf((float)rx.y, r.ixy.x, r.cxx), fmaf((float)ry.y, r.ixy.y, r.cxy)), fminf(fmaf((float)rz.y, r.izz.x, r.cxz), best_hi));
+                hl = tl <= fl; hr = tr <= fr;
+                cl = (int)n1.z; cr = (int)n1.w;
             } else { // 64-byte record: l.lo.xy l.hi.xy | r.lo.xy r.hi.xy | l.lo.z l.hi.z r.lo.z r.hi.z | left, right
                 const float4 *q = reinterpret_cast<const float4 *>(nodes + (unsigned)node);
                 const float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
@@ -754,7 +779,7 @@ __device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, 
     for (int k = 0; k < sc.n_big; ++k) exact_prim_test<R>(exact12, sc.big_idx[k], sc.big_idx[k], P, a, tmin, behind_ok, best_t, best_i);
     // 2. the tree
     auto leaf = [&](int code) { exact_prim_test_lane<R>(exact12, code, P, a, tmin, behind_ok, best_t, best_i); };
-    auto best = [&]() { return best_t < R(3.0e38) ? float_up((double)best_t) : 3.4028235e38f; };
+    auto best = [&]() { return (best_t < R(3.0e38) ? float_up((double)best_t) : 3.4028235e38f) + 0.0f; };
     bvh_traverse<COUNT>(sc, stack, r, leaf, best, cnt);
     // 3. a ray outside the shutter interval: the MovingSphere boxes were built for [t_lo, t_hi], so test every moving sphere exactly
     if (!r.time_ok)
@@ -942,7 +967,7 @@ __device__ inline void scan_all_cull_ext(SceneRef sc, const Path<double> &P, dou
     }
 }
 
-__device__ inline float ext_best_hi(const ExtHit &H) { return H.t < 3.0e38 ? float_up(H.t) : 3.4028235e38f; }
+__device__ inline float ext_best_hi(const ExtHit &H) { return (H.t < 3.0e38 ? float_up(H.t) : 3.4028235e38f) + 0.0f; }
 
 __device__ inline void scan_bvh_ext(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, ExtHit &H) {
     const BvhRay r = make_bvh_ray(sc, P, a, tmin);
