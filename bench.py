@@ -45,6 +45,7 @@ CONFIGS = {
     "FINAL": (500, 500, 128, 0, False, None),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md: L2 aggregate ~34.5 TB/s
 SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; VALU issue peak = 1024 x 2.4e9 SIMD-cycles / s
 FP64_PEAK_TFLOPS = 78.6
 FP32_PEAK_TFLOPS = 157.3
@@ -117,24 +118,33 @@ def roofline(cfg, accel, precision, n_prims, launch_s, launches_per_step, counts
     rec = 32 if precision == "f64" else 16
     out = {"kernel": "trace_kernel<%s,%s>" % (precision, "BVH" if accel == "bvh" else "flat scan + FP32 cull"),
            "launch_ms": round(launch_s * 1e3, 4), "launches_per_step": launches_per_step}
+    scene_bytes = n_prims * (32.0 + 96.0 + 8.0) + 4096.0  # node record + exact record + (kind, material) per primitive, + materials / camera
     if accel == "bvh":
         visits, leaves = counts["aabb_tests"] * per / 2.0, counts["prim_tests"] * per
-        bytes_alg = visits * 32.0 + leaves * 32.0 + S * 96.0 + smp * 24.0 + pix * 12.0
-        model = ("algorithmic bytes = inner-node visits x 32 (one half-plane node record) + exact primitive tests x 32 (cx cy cz r^2) + "
-                 "segments x 96 (material record) + samples x 24 (per-sample colour) + pixels x 12")
+        fetch = visits * 32.0 + leaves * 32.0 + S * 96.0
+        fetch_model = "inner-node visits x 32 (one half-plane node record) + exact primitive tests x 32 (cx cy cz r^2) + segments x 96 (material record)"
     else:
-        bytes_alg = S * n_prims * rec / 256.0 + pix * 12.0
-        model = "algorithmic bytes = S*N*REC/256 + 12*pixels (SURVEY.md 8d: the Hitlist scan with a 256-ray LDS tile)"
+        fetch = S * n_prims * rec / 256.0
+        fetch_model = "S*N*REC/256 (SURVEY.md 8d: the Hitlist scan with a 256-ray LDS tile)"
         out["flat_scan_flops"] = {"achieved": round(S * (n_prims * 20.0 + 120.0) / launch_s / 1e12, 3), "unit": "TFLOP/s",
                                   "peak": FP64_PEAK_TFLOPS if precision == "f64" else FP32_PEAK_TFLOPS,
                                   "note": "reference-equivalent flops S*(20N+120) of SURVEY.md 8d; the FP32 cull skips most FP64 work, so this "
                                           "is work avoided, not ALU utilisation"}
+    # HBM: what the launch must move to / from memory at least once -- the scene in, one colour per sample out
+    bytes_alg = scene_bytes + smp * 24.0
     hbm_gbs = bytes_alg / launch_s / 1e9
     out["hbm"] = {"achieved": round(hbm_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 5),
-                  "algorithmic_bytes_per_launch": round(bytes_alg), "model": model, "target_40pct_met": False,
-                  "note": "the north star's >= 40 % of the HBM-read roofline is NOT met and cannot be by this design: the scene (<= 1 MB) "
-                          "stays on chip (scalar cache / L1 / L2), so the kernel's HBM traffic is the per-sample colours it writes, not "
-                          "scene reads (SURVEY.md 8d says the same of any on-chip-reuse design)"}
+                  "algorithmic_bytes_per_launch": round(bytes_alg), "model": "scene once (%d B) + samples x 24 B (the per-sample colour the in-order reduction reads back)" % scene_bytes,
+                  "target_40pct_met": False,
+                  "note": "the north star's >= 40 % of the HBM-read roofline is NOT met and cannot be by this design: the scene (<= 1.4 MB) stays on "
+                          "chip, so HBM sees the per-sample colours, not scene reads (SURVEY.md 8d says the same of any on-chip-reuse design)"}
+    # the per-ray fetches the traversal and shading issue (served by L1 / L2, not HBM)
+    fetch_gbs = fetch / launch_s / 1e9
+    out["on_chip_fetch"] = {"achieved": round(fetch_gbs, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(fetch_gbs / L2_PEAK_GBS, 4),
+                            "bytes_per_launch": round(fetch), "model": fetch_model, "as_fraction_of_hbm_peak": round(fetch_gbs / HBM_PEAK_GBS, 4),
+                            "note": "per-lane node / primitive / material fetches over the launch time, against the aggregate L2 bandwidth; the same "
+                                    "bytes against the HBM peak (as_fraction_of_hbm_peak) would be near or above 1: the caches' reuse of the scene is "
+                                    "what keeps this path off the HBM roofline"}
     prof = None
     try:
         allp = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json")))

@@ -446,9 +446,9 @@ def test_bench_json_schema():
     assert d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["value"] > 100
     assert d["config"]["workload"].startswith("C3: 1920x1080x256spp") and d["config"]["spheres"] > 9900 and d["config"]["frames_in_flight"] == 1
     rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm", "launch_ms", "launches_per_step"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm", "on_chip_fetch", "launch_ms", "launches_per_step"):
         assert k in rf, k
-    assert rf["bound"] == "valu" and 0 < rf["hbm"]["frac"] < 1 and (rf["frac"] is None or 0 < rf["frac"] <= 1)
+    assert rf["bound"] == "valu" and 0 < rf["hbm"]["frac"] < 1 and 0 < rf["on_chip_fetch"]["frac"] < 1 and (rf["frac"] is None or 0 < rf["frac"] <= 1)
     assert rf["launch_ms"] * rf["launches_per_step"] <= d["ms_per_step"] * 1.02, "a kernel cannot take longer than the step it is in"
     assert d["aabb_tests_per_segment"] > 2 and d["prim_tests_per_segment"] >= 2
     assert d["pipelined"]["value"] > 100 and d["c2"]["value"] > 100 and d["c4"]["value"] > 100 and d["c2"]["workload"].startswith("C2: 800x400x64spp")
