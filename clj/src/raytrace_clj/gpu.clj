@@ -79,12 +79,21 @@
   Object       (leaves [this c f l] (throw (ex-info (str (type this) " is not supported on the GPU path")
                                                     {:unsupported-on-gpu-path (type this)}))))
 
+(defn- leaf-id-fn
+  "object IDENTITY -> small integer (an IdentityHashMap, not System/identityHashCode: that is a 31-bit hash and two of the
+  ~10 000 spheres of the cover scene at n = 50 collide with probability ~2 %)"
+  []
+  (let [ids (java.util.IdentityHashMap.)]
+    (fn [leaf]
+      (or (.get ids leaf)
+          (let [k (.size ids)] (.put ids leaf k) k)))))
+
 (defn- dedup-leaves
   "a one-item make-bvh stores the same child twice (hitable.clj:113-114): drop repeats of the same record under the
   same instance chain (the same record under two different instances is two primitives)"
-  [xs]
+  [lid xs]
   (let [seen (java.util.HashSet.)]
-    (filterv #(.add seen [(System/identityHashCode (:leaf %)) (:chain %) (:flip %)]) xs)))
+    (filterv #(.add seen [(lid (:leaf %)) (:chain %) (:flip %)]) xs)))
 
 (defn- intern! [table obj build]
   ;; table: atom {:ids IdentityHashMap, :rows []}; children are interned first
@@ -153,14 +162,15 @@
   [{:keys [camera world]}]
   (reset! images [])
   (let [called    (vec (leaves world [] 0 false))          ; hit? invocation order, repeats included
-        world-es  (dedup-leaves called)
-        key-of    (fn [e] [(System/identityHashCode (:leaf e)) (:chain e) (:flip e)])
+        lid       (leaf-id-fn)
+        world-es  (dedup-leaves lid called)
+        key-of    (fn [e] [(lid (:leaf e)) (:chain e) (:flip e)])
         index-of  (zipmap (map key-of world-es) (range))
         media-calls (mapv #(index-of (key-of %)) (filter #(instance? ConstantMedium (:leaf %)) called))
         ;; every medium's boundary is flattened on its own and appended AFTER the world (kind | 16)
         bounds    (reduce (fn [acc [i e]]
                             (if (instance? ConstantMedium (:leaf e))
-                              (let [b (dedup-leaves (leaves (:boundary (:leaf e)) (:chain e) (:flip e) false))]
+                              (let [b (dedup-leaves (leaf-id-fn) (leaves (:boundary (:leaf e)) (:chain e) (:flip e) false))]
                                 (-> acc
                                     (assoc-in [:range i] [(+ (count world-es) (count (:prims acc))) (count b)])
                                     (update :prims into b)))
@@ -263,6 +273,43 @@
         {:rgb8 rgb :linear lin :total-rays (aget cnt 0) :total-pixels (aget cnt 1)}
         (finally (call-int "rtmi_scene_destroy" (.getValue scn))))
       (finally (call-int "rtmi_shutdown" (.getValue ctx))))))
+
+(defn render-multi
+  "The same on every GPU in `devices` from this one JVM (rtmi_render_multi): one context per device, the scene created on
+  the first and cloned onto the others (rtmi_scene_clone), the 8x8 tiles of the frame dealt round-robin, ONE ncclGather
+  inside the library, assembled on the first device.  Returns what `render` returns; :total-rays is the sum over the devices.
+  The image is bit-identical to `render`'s."
+  [scene nx ny ns & {:keys [depth seed devices precision] :or {depth 50 seed 0x5eed0002 devices [0] precision 0}}]
+  (let [f     (flatten-scene scene)
+        npx   (* nx ny)
+        lin   (double-array (* 3 npx))
+        rgb   (byte-array (* 3 npx))
+        cnt   (long-array 2)
+        ctxs  (mapv (fn [d] (let [c (PointerByReference.)] (check (call-int "rtmi_init" (int d) (int 0) c)) (.getValue c))) devices)
+        scn0  (PointerByReference.)]
+    (try
+      (check (call-int "rtmi_scene_create_ex" (first ctxs)
+                       (int (:n-prims f)) (:prim-kind f) (:prim-geom f) (:prim-mat f)
+                       (int (:n-mats f)) (:mat-kind f) (:mat-tex f) (:mat-param f)
+                       (int (:n-tex f)) (:tex-kind f) (:tex-param f) (:tex-child f)
+                       (:cam-kind f) (:cam f)
+                       (:prim-flip f) (:prim-xform f) (int (:n-xforms f)) (:xform-kind f) (:xform-param f) scn0))
+      (when (:uses-perlin f)
+        (check (call-int "rtmi_scene_set_perlin" (.getValue scn0)
+                         (double-array (mapcat v3 perlin/random-vectors))
+                         (int-array (concat perlin/perm-x perlin/perm-y perlin/perm-z)))))
+      (when (pos? (alength ^ints (:media-calls f)))
+        (check (call-int "rtmi_scene_set_media_calls" (.getValue scn0) (int (alength ^ints (:media-calls f))) (:media-calls f))))
+      ;; (ImageMap pixels: as in `render`, before cloning -- the clone carries everything set on the original)
+      (let [clones (mapv (fn [c] (let [s (PointerByReference.)] (check (call-int "rtmi_scene_clone" (.getValue scn0) c s)) (.getValue s)))
+                         (rest ctxs))
+            scenes (into [(.getValue scn0)] clones)]
+        (try
+          (check (call-int "rtmi_render_multi" (int (count scenes)) (into-array com.sun.jna.Pointer scenes)
+                           (int nx) (int ny) (int ns) (int depth) (long seed) (int precision) lin rgb cnt))
+          {:rgb8 rgb :linear lin :total-rays (aget cnt 0) :total-pixels (aget cnt 1)}
+          (finally (doseq [s scenes] (call-int "rtmi_scene_destroy" s)))))
+      (finally (doseq [c ctxs] (call-int "rtmi_shutdown" c))))))
 
 (defn save-ppm
   "imagez `save` (core.clj:112) has no PPM writer; binary P6 written here"
