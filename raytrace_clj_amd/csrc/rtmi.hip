@@ -851,6 +851,9 @@ struct BvhBuilder {
     double delta = 0.0;
     int leaf_code(int idx) const { return ~(idx | (moving[(size_t)idx] ? 0x40000000 : 0)); }
     int sah_depth = 8, max_depth = 0;
+    double min_frac = 0.0;    // experiments: RTMI_BVH_MIN_FRAC = smallest share of a node's primitives a child may get (balance)
+    int sweep_max = 0;  // subtrees up to this many primitives: exact sweep SAH; above: 32 bins (build time)
+    int sah_levels = 1 << 20; // experiments: RTMI_BVH_SAH_LEVELS = number of top levels split by SAH (median below)
     BvhBox bounds(int b, int e) const { BvhBox r = box_empty(); for (int i = b; i < e; ++i) box_grow(r, items[(size_t)i].b); return r; }
     // node record (16 floats): l.lo.xy l.hi.xy | r.lo.xy r.hi.xy | l.lo.z l.hi.z r.lo.z r.hi.z | left, right, 0, 0
     void put_box(int node, int side, const BvhBox &b) {
@@ -876,7 +879,38 @@ struct BvhBuilder {
         for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
         int mid = (b + e) / 2;
         bool done = false;
-        if (depth < sah_depth && e - b > 2) {
+        // SAH wherever the subtree can still be finished by median splits within the stack's depth: depth + ceil(log2(count)) + 1
+        // levels at most (a global cap on the SAH depth left the deep, crowded parts of large scenes to median splits)
+        int lgc = 1;
+        while ((1 << lgc) < e - b) ++lgc;
+        if (depth + lgc + 1 < sah_depth && e - b > 2 && depth < sah_levels && e - b <= sweep_max) {
+            // exact sweep SAH: for each axis sort by centroid, try every split position (suffix boxes, then one forward pass)
+            double best = 1e300; int best_pos = -1;
+            const int n = e - b;
+            std::vector<BvhItem> tmp((size_t)n), best_order;
+            std::vector<double> suffix((size_t)n + 1);
+            for (int ax = 0; ax < 3; ++ax) {
+                if (!(chi[ax] - clo[ax] > 0)) continue;
+                std::copy(items.begin() + b, items.begin() + e, tmp.begin());
+                std::sort(tmp.begin(), tmp.end(), [&](const BvhItem &x, const BvhItem &y) { return x.cen[ax] < y.cen[ax] || (x.cen[ax] == y.cen[ax] && x.idx < y.idx); });
+                BvhBox acc = box_empty();
+                for (int i = n - 1; i > 0; --i) { box_grow(acc, tmp[(size_t)i].b); suffix[(size_t)i] = box_area(acc); }
+                acc = box_empty();
+                bool improved = false;
+                for (int i = 0; i < n - 1; ++i) { // left = [0, i], right = [i+1, n)
+                    box_grow(acc, tmp[(size_t)i].b);
+                    const double cost = box_area(acc) * (i + 1) + suffix[(size_t)i + 1] * (n - 1 - i);
+                    if (std::min(i + 1, n - 1 - i) < min_frac * n) continue;
+                    if (cost < best) { best = cost; best_pos = i + 1; improved = true; }
+                }
+                if (improved) best_order = tmp;
+            }
+            if (best_pos > 0) {
+                std::copy(best_order.begin(), best_order.end(), items.begin() + b);
+                mid = b + best_pos;
+                done = true;
+            }
+        } else if (depth + lgc + 1 < sah_depth && e - b > 2 && depth < sah_levels) {
             const int NB = 32;
             double best = 1e300; int best_k = -1, best_axis = -1;
             for (int ax = 0; ax < 3; ++ax) {
@@ -895,6 +929,7 @@ struct BvhBuilder {
                 for (int k = 0; k < NB - 1; ++k) {
                     box_grow(acc, bb[k]); n += cnt[k];
                     if (n == 0 || rc[k + 1] == 0) continue;
+                    if (std::min(n, rc[k + 1]) < min_frac * (e - b)) continue;
                     const double cost = box_area(acc) * n + box_area(right[k + 1]) * rc[k + 1];
                     if (cost < best) { best = cost; best_k = k; best_axis = ax; }
                 }
@@ -1010,7 +1045,11 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
     } else {
         int lg = 1;
         while ((1u << lg) < B.items.size()) ++lg;
-        B.sah_depth = std::max(2, RTMI_BVH_STACK - 2 - lg); // SAH levels + median levels (<= lg) stay below the stack size
+        if (const char *e = std::getenv("RTMI_BVH_SAH_LEVELS")) B.sah_levels = std::atoi(e);
+        if (const char *e = std::getenv("RTMI_BVH_SWEEP_MAX")) B.sweep_max = std::atoi(e);
+        if (const char *e = std::getenv("RTMI_BVH_MIN_FRAC")) B.min_frac = std::atof(e);
+        B.sah_depth = RTMI_BVH_STACK - 2; // depth budget: a node at depth d over k primitives may use SAH while d + ceil(log2 k) + 1 < budget
+        (void)lg;
         d.bvh_root = B.build(0, (int)B.items.size(), 0);
         if (B.max_depth >= RTMI_BVH_STACK - 1 || B.nodes.size() / 16 >= (1u << 25)) { // cannot happen by construction / node byte offsets are 31-bit
             d.bvh_root = RTMI_BVH_EMPTY; d.n_big = 0; d.bvh_obound = -1.0f; // obound < 0: every ray takes the exact flat scan

@@ -178,6 +178,67 @@ template <typename R> __device__ inline void rand_in_unit_sphere(Path<R> &P, R &
         if (!(dot3(x, y, z, x, y, z) >= R(1.0))) return;
     }
 }
+// The same for the lanes with `need`, evaluated COOPERATIVELY when the whole wave is here (every lane of the wave calls; the
+// lanes without `need` help).  In the plain loop a wave retries until its unluckiest lane accepts (acceptance pi/6: ~5 trips for
+// ~35 lanes) while the lanes that already hold a sample idle.  The stream is random access -- candidate c of a lane's stream is
+// draws 3c+1 .. 3c+3 after its current position -- so after RTMI_SAMPLER_PLAIN ordinary trips the n lanes still without a sample
+// ("victims") get K = 64/n candidates each evaluated at once, one per lane: lane L takes candidate floor(L/n) of victim L mod n.
+// A victim takes its FIRST accepted candidate (util.clj:49-52: candidates are tried in order) and advances its stream past it,
+// i.e. by exactly the draws the sequential loop would have consumed; with no accepted candidate it advances by 3K and goes on.
+#ifndef RTMI_COOP_SAMPLER
+#define RTMI_COOP_SAMPLER 1
+#endif
+#ifndef RTMI_SAMPLER_PLAIN
+#define RTMI_SAMPLER_PLAIN 2
+#endif
+template <typename R> __device__ inline void rand_in_unit_sphere_wave(Path<R> &P, bool need, R &x, R &y, R &z) {
+#if RTMI_COOP_SAMPLER
+    if (__ballot(1) != ~0ull) { // part of the wave is elsewhere (it cannot help): the plain loop
+        if (need) rand_in_unit_sphere(P, x, y, z);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    bool pending = need;
+    for (int trip = 0; trip < RTMI_SAMPLER_PLAIN; ++trip) {
+        if (__ballot(pending) == 0) return;
+        if (pending) {
+            x = next_symmetric(P); y = next_symmetric(P); z = next_symmetric(P);
+            pending = dot3(x, y, z, x, y, z) >= R(1.0);
+        }
+    }
+    u64 rem = __ballot(pending);
+    while (rem) { // wave-uniform
+        const int n = __popcll(rem), K = 64 / n;
+        const int vrank = __popcll(rem & ((1ull << lane) - 1ull));
+        // victims to the front (by rank), everyone else behind them: a permutation of the 64 lanes; lane i < n then knows victim i
+        const int dest = pending ? vrank : n + (lane - vrank);
+        const int tbl = __builtin_amdgcn_ds_permute(dest << 2, lane);
+        const unsigned M = (unsigned)(65536.0f / (float)n) + 1u;          // (L * M) >> 16 = floor(L / n) for L < 64, n <= 64
+        const int c = (int)(((unsigned)lane * M) >> 16), j = lane - c * n; // this lane: candidate c of victim j
+        const int vic = __builtin_amdgcn_ds_bpermute(j << 2, tbl);
+        const u64 rs_c = __shfl(P.rs, vic) + RTMI_GOLD * (u64)(3 * c);
+        const R cx = Real<R>::symmetric(mix64(rs_c + RTMI_GOLD)), cy = Real<R>::symmetric(mix64(rs_c + 2ull * RTMI_GOLD)),
+                cz = Real<R>::symmetric(mix64(rs_c + 3ull * RTMI_GOLD));
+        const u64 acc = __ballot(c < K && !(dot3(cx, cy, cz, cx, cy, cz) >= R(1.0)));
+        u64 sm = 0; // the lanes that hold one victim's candidates, relative to its rank: 0, n, 2n, ...
+        for (int q = 0; q < K; ++q) sm |= 1ull << (q * n);
+        const u64 mine = pending ? ((acc >> vrank) & sm) : 0ull;
+        const int first = mine ? __ffsll((long long)mine) - 1 : 0;
+        const int src = mine ? vrank + first : lane;
+        const R fx = __shfl(cx, src), fy = __shfl(cy, src), fz = __shfl(cz, src);
+        if (pending) {
+            const unsigned used = mine ? 3u * (unsigned)(__popcll(sm & ((1ull << first) - 1ull)) + 1) : 3u * (unsigned)K;
+            P.rs += RTMI_GOLD * (u64)used;
+            P.ctr += used;
+            if (mine) { x = fx; y = fy; z = fz; pending = false; }
+        }
+        rem = __ballot(pending);
+    }
+#else
+    if (need) rand_in_unit_sphere(P, x, y, z);
+#endif
+}
+
 // util.clj:32-41 rand-in-unit-disk
 template <typename R> __device__ inline void rand_in_unit_disk(Path<R> &P, R &x, R &y) {
     for (;;) {
@@ -1147,7 +1208,7 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
     // phase 2 -- rand-in-unit-sphere: Lambertian (shader.clj:32) and Metal (shader.clj:53; drawn even when fuzz = 0)
     R rx = R(0), ry = R(0), rz = R(0);
     RTMI_SUBSTAMP(9)
-    if (is_lamb || is_metal || is_iso) rand_in_unit_sphere(P, rx, ry, rz);
+    rand_in_unit_sphere_wave(P, is_lamb || is_metal || is_iso, rx, ry, rz);
     RTMI_SUBSTAMP(10)
     // phase 3 -- directions
     if (is_lamb) { // shader.clj:29-34: target = (p + normal) + rand; dir = target - p
