@@ -76,6 +76,7 @@ struct TraceParams {
     int n_ptiles;          // number of LDS tiles the static spheres are cut into
     unsigned *queue;       // work queue head of this pass (zeroed before the launch): next unclaimed work item
     unsigned total_items;  // n_local_tiles * s_count * 64
+    unsigned qblock;       // work items a wave claims per queue access (a multiple of 64)
     int rx0, ry0, rx1, ry1; // output region (row 0 = top): pixels outside it are not traced (whole frame: 0, 0, nx, ny)
     u64 *trav;             // COUNT instantiations: [0] += AABB slab tests (metrics aabb.intersection.total, hitable.clj:39), [1] += exact primitive tests
 };
@@ -85,7 +86,7 @@ struct TraceParams {
 #ifndef RTMI_STASH
 #define RTMI_STASH 1 // camera rays generated 64 at a time at full wave width into a register stash (0: per trip, for the dead lanes only)
 #endif
-constexpr unsigned kQueueBlock = RTMI_QUEUE_BLOCK; // work items a wave claims per queue access: 4 chunks = one tile x 4 consecutive samples
+constexpr unsigned kQueueBlock = RTMI_QUEUE_BLOCK; // work items a wave claims per queue access at least: 4 chunks = one tile x 4 consecutive samples
 
 template <typename R> __device__ inline const R *stat4_of(SceneRef sc);
 // Stage static spheres [first, first+count) into LDS as {cx, cy, cz, r*r} (hitable.clj:188: (* radius radius)).
@@ -243,11 +244,11 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
                 if (exhausted) break;
                 if (w_cur == w_end) {
                     unsigned base = 0;
-                    if (lane == 0) base = atomicAdd(tp.queue, kQueueBlock);
+                    if (lane == 0) base = atomicAdd(tp.queue, tp.qblock);
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (base >= total_items) { exhausted = true; break; }
                     w_cur = base;
-                    w_end = min(base + kQueueBlock, total_items); // total_items and kQueueBlock are multiples of 64
+                    w_end = min(base + tp.qblock, total_items); // total_items and qblock are multiples of 64
                 }
                 const unsigned m = w_cur + (unsigned)lane;
                 w_cur += 64u;
@@ -764,6 +765,14 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             HIP_TRY(hipEventRecord(e0, st));
         }
         tp.queue = queue; tp.total_items = (unsigned)((long long)n_local * s_count * 64);
+        { // claim size: one global atomic per claim -- 256 items on small launches (a short tail matters more), up to 1024 when a wave has
+          // thousands of claims ahead of it (C3: 129 000 items per wave)
+            const long long per_wave = (long long)tp.total_items / std::max(1, c->cus * 16);
+            unsigned qb = kQueueBlock;
+            while (qb < 1024u && per_wave >= (long long)qb * 128) qb *= 2;
+            if (const char *e = std::getenv("RTMI_QUEUE_BLOCK_RT")) qb = std::max(64, std::atoi(e) / 64 * 64);
+            tp.qblock = qb;
+        }
         tp.rx0 = std::max(rg[0], 0); tp.ry0 = std::max(rg[1], 0); tp.rx1 = std::min(rg[2], nx); tp.ry1 = std::min(rg[3], ny);
         tp.trav = reinterpret_cast<u64 *>(c->counters.p) + 3;
         HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned), st));
