@@ -184,13 +184,21 @@ class FramePipeline:
         """enqueue one frame on the next slot; returns that slot's TileRenderer (its buffers are valid after sync())"""
         ctx, ds, tr, stream = self.slots[self.next]
         self.next = (self.next + 1) % len(self.slots)
+        if tr.world == 1 and len(self.slots) > 1:
+            # one GPU, several frames in flight: every slot runs on its CONTEXT'S OWN stream (stream = NULL in the C-ABI).  The HIP
+            # runtime deals streams to a few hardware queues in creation order; the contexts' streams are created back to back and
+            # land on different queues, whereas extra torch streams were seen to share one queue (kernels of two frames then
+            # run one after the other, no overlap).  No torch work is queued between frames, so nothing needs ordering with torch.
+            tr._step(None, ns, kw.get("depth", 50), kw.get("seed", 0x5EED0002), kw.get("precision", "f64"))
+            return tr
         with torch.cuda.stream(stream):
             tr.step(ns, **kw)
         return tr
 
     def sync(self):
-        for _, _, _, stream in self.slots:
+        for ctx, _, _, stream in self.slots:
             stream.synchronize()
+        torch.cuda.synchronize(self.slots[0][0].device)  # the contexts' own streams
 
     def last_trace_ms(self):
         """(sum of trace-kernel durations in ms, number of launches) over all slots since the last call"""
