@@ -1683,6 +1683,7 @@ RTMI_EXPORT int rtmi_scene_clone(rtmi_scene *src, rtmi_ctx *ctx, rtmi_scene **ou
     if (!scene_ok(src)) return fail(RTMI_E_STATE, "invalid scene handle");
     if (!ctx_ok(ctx)) return fail(RTMI_E_STATE, "invalid context handle");
     if (!out_scene) return fail(RTMI_E_ARG, "out_scene is NULL");
+    DeviceGuard guard;
     const rtmi_scene::Args &A = src->args;
     rtmi_scene *s = nullptr;
     int rc = rtmi_scene_create_ex(ctx, src->n_prims, A.prim_kind.data(), A.prim_geom.data(), A.prim_mat.data(), src->n_mats, A.mat_kind.data(), A.mat_tex.data(),
@@ -1748,6 +1749,12 @@ int ensure_event(hipEvent_t *e) {
     if (!*e) HIP_TRY(hipEventCreate(e));
     return RTMI_OK;
 }
+// the multi-device entries switch the calling thread's current device; hosts that track it themselves (PyTorch) get it back
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 } // namespace
 
 RTMI_EXPORT int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed,
@@ -1761,6 +1768,7 @@ RTMI_EXPORT int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, i
         if (scenes[r]->n_prims != scenes[0]->n_prims) return fail(RTMI_E_ARG, "replica %d is not a clone of replica 0", r);
     }
     std::lock_guard<std::mutex> lock(g_multi_mu);
+    DeviceGuard guard;
     const int ntiles = tiles_x_of(nx) * tiles_y_of(ny);
     const int per = (ntiles + n - 1) / n;                  // every replica's record is padded to this many tiles
     const size_t rec = (size_t)per * 192 + 2;              // 8-byte words per record: tiles [per][64][3] doubles + the two metrics counters
@@ -1842,6 +1850,7 @@ RTMI_EXPORT int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, i
 RTMI_EXPORT int rtmi_render_multi(int32_t n, rtmi_scene *const *scenes, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed, int32_t precision,
                                   double *out_linear, uint8_t *out_rgb8, uint64_t *out_counters) {
     if (n <= 0 || !scenes || !scene_ok(scenes[0])) return fail(RTMI_E_ARG, "bad replica list");
+    DeviceGuard guard;
     rtmi_ctx *c0 = scenes[0]->ctx;
     HIP_TRY(hipSetDevice(c0->device));
     const size_t npx = (size_t)nx * (size_t)ny;
