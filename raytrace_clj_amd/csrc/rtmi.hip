@@ -581,6 +581,13 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(RTMI_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// the multi-device entries switch the calling thread's current device; hosts that track it themselves (PyTorch) get it back
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -1749,12 +1756,6 @@ int ensure_event(hipEvent_t *e) {
     if (!*e) HIP_TRY(hipEventCreate(e));
     return RTMI_OK;
 }
-// the multi-device entries switch the calling thread's current device; hosts that track it themselves (PyTorch) get it back
-struct DeviceGuard {
-    int prev = -1;
-    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
 } // namespace
 
 RTMI_EXPORT int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed,
