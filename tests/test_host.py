@@ -285,3 +285,23 @@ def test_image_map_reads_png(tmp_path):
     assert np.array_equal(texture.decode_png(encode(grey, 0, [2, 4])), np.repeat(grey, 3, axis=2))
     with pytest.raises(ValueError):
         texture.decode_png(b"not a png")
+
+
+# ---- bench.py's roofline arithmetic (no GPU: synthetic counters) ----------------------------------------------------------
+def test_bench_roofline_object_is_consistent():
+    """every fraction bench.py prints is a fraction (<= 1) for counter values of the size the GPU reports, the PMC import is
+    stamped with the kernel sources it was taken with, and a workload without a profile still yields the schema's keys"""
+    import bench
+    counts = {"segments": 1.43e9, "samples": 5.3e8, "pixels": 1920 * 1080, "aabb_tests": 4.34e10, "prim_tests": 4.35e9}
+    rf = bench.roofline("C3", "bvh", "f64", 10001, 0.0971, 1, counts)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm", "on_chip_fetch", "launch_ms", "launches_per_step", "kernel"):
+        assert k in rf, k
+    assert rf["bound"] == "valu" and 0 < rf["hbm"]["frac"] < 0.05 and 0 < rf["on_chip_fetch"]["frac"] < 1 and rf["hbm"]["target_40pct_met"] is False
+    assert rf["on_chip_fetch"]["as_fraction_of_hbm_peak"] > rf["on_chip_fetch"]["frac"]
+    if rf["frac"] is not None:  # profiles/pmc_counters.json holds C3/bvh/f64
+        assert 0 < rf["frac"] <= 1 and rf["traffic"] > 0 and rf["counts"]["kernel_sha"] and isinstance(rf["counts"]["stale"], bool)
+        assert 0.3 < rf["lanes_active"] <= 1
+    none = bench.roofline("C1", "bvh", "f64", 488, 1e-3, 1, dict(counts, segments=2e5, samples=8e4, pixels=2e4, aabb_tests=4e6, prim_tests=6e5))
+    assert none["frac"] is None and none["traffic"] is None and none["hbm"]["frac"] < 1
+    flat = bench.roofline("C2", "flat", "f64", 488, 9.3e-3, 1, dict(counts, segments=5.24e7, samples=2.05e7, pixels=3.2e5))
+    assert "flat_scan_flops" in flat and flat["on_chip_fetch"]["frac"] < 1
