@@ -802,6 +802,9 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         int resident = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, kTraceBlock, dyn_lds));
         const int grid_trace = std::max(1, c->cus * std::max(1, std::min(c->blocks_per_cu * (256 / kTraceBlock), resident)));
+        if (c->last_grid != grid_trace && std::getenv("RTMI_DEBUG"))
+            fprintf(stderr, "[rtmi] trace launch: %d workgroups of %d threads (%d resident per CU by the occupancy query, cap %d), %zu B LDS each\n",
+                    grid_trace, kTraceBlock, resident, c->blocks_per_cu * (256 / kTraceBlock), dyn_lds);
         c->last_grid = grid_trace;
         hipLaunchKernelGGL(kern, dim3(grid_trace), dim3(kTraceBlock), dyn_lds, st, s->d_dev, tp);
         HIP_TRY(hipGetLastError());
