@@ -1481,6 +1481,13 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
             MatRec r;
             std::memset(&r, 0, sizeof(r));
             r.mat_kind = mat_kind[m]; r.tex = mat_tex[m]; r.param = mat_param[m];
+            if (mat_kind[m] == RTMI_MAT_DIELECTRIC) { // one IEEE operation each, as the kernel would evaluate them per scatter
+                const volatile double ri = mat_param[m];
+                const volatile double inv = 1.0 / ri, num = 1.0 - ri, den = 1.0 + ri;
+                const volatile double q = num / den;
+                const volatile double r0 = q * q;
+                r.inv_ri = inv; r.r0 = r0;
+            }
             r.tex_kind = (r.tex >= 0 && r.tex < n_tex) ? tex_kind[r.tex] : -1;
             if (r.tex_kind == RTMI_TEX_CONSTANT) { const double *tp = tex_param + (size_t)r.tex * RTMI_TEX_STRIDE; r.r = tp[0]; r.g = tp[1]; r.b = tp[2]; }
             if (r.tex_kind == RTMI_TEX_CHECKER) { // both children Constant: the whole texture fits the record

@@ -1083,7 +1083,10 @@ template <typename R> struct HitRec { R t, px, py, pz, nx, ny, nz, u, v; int ori
 // tex_kind = RTMI_TEX_CHECKER2 (record-only code): a Checkerboard of two Constant textures -- the two colours and the scale are in
 // the record as well (r,g,b = tex0 = the colour where the sine product is negative; c1 = tex1), texture.clj:44-50.
 #define RTMI_TEX_CHECKER2 100
-struct __attribute__((aligned(16))) MatRec { int mat_kind, tex, tex_kind, pad; double param, r, g, b; double scale, c1r, c1g, c1b; double pad2[2]; };
+// Dielectric: inv_ri = 1/ri (shader.clj:89) and r0 = ((1-ri)/(1+ri))^2 (schlick, shader.clj:71-72) depend on the material only: the
+// host evaluates the same IEEE operations once per material instead of two FP64 divisions per scatter (FP64 kernels; RTMI_F32 evaluates
+// them in float as before)
+struct __attribute__((aligned(16))) MatRec { int mat_kind, tex, tex_kind, pad; double param, r, g, b; double scale, c1r, c1g, c1b; double inv_ri, r0; };
 
 // `all_uv`: the probes report uv of every UVSphere hit; the trace kernel computes it (atan2 + asin) only where the hit material's
 // texture reads uv (bit RTMI_PRIM_NEEDS_UV of the device copy of prim_kind: e.g. not for a constant-colour sky dome).
@@ -1230,15 +1233,16 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
         const R dn = dot3(P.dx, P.dy, P.dz, nx, ny, nz);
         R onx, ony, onz, eta, cosine;
         if (dn > R(0)) { onx = -nx; ony = -ny; onz = -nz; eta = ri; cosine = ri * (dn / dmag); }
-        else { onx = nx; ony = ny; onz = nz; eta = R(1.0) / ri; cosine = -(dn / dmag); }
+        else { onx = nx; ony = ny; onz = nz; eta = sizeof(R) == sizeof(double) ? (R)mq[5].x : R(1.0) / ri; cosine = -(dn / dmag); }
         const R dt = dot3(ux, uy, uz, onx, ony, onz);
         const R disc = R(1.0) - (eta * eta) * (R(1.0) - dt * dt);
         // reflect(ray-direction, normal): un-normalised d, original normal
         const R k = R(2.0) * dn;
         sdx = P.dx - k * nx; sdy = P.dy - k * ny; sdz = P.dz - k * nz;
         if (disc > R(0)) {
-            R r0 = (R(1.0) - ri) / (R(1.0) + ri);
-            r0 = r0 * r0;
+            R r0;
+            if (sizeof(R) == sizeof(double)) r0 = (R)mq[5].y;
+            else { r0 = (R(1.0) - ri) / (R(1.0) + ri); r0 = r0 * r0; }
             const R prob = r0 + (R(1.0) - r0) * pow5(R(1.0) - cosine);
             if (!(next_uniform(P) < prob)) { // one draw, only when refraction is possible (shader.clj:91-93)
                 const R sq = Real<R>::sqrt_(disc);
