@@ -153,6 +153,9 @@ def roofline(cfg, accel, precision, n_prims, launch_s, launches_per_step, counts
         pass
     if prof:
         sha = kernel_sha()
+        # the profile's counters are per launch of the profiled (one-GPU) run: x its launches per frame = per frame; this GPU executes
+        # `share` of the frame in `launches_per_step` launches
+        share = share * prof.get("launches_per_frame", 1) / max(1, launches_per_step)
         fp64 = prof["valu_fp64"] * share
         other = (prof["valu_total"] - prof["valu_fp64"]) * share
         issue_cycles = fp64 * 4.0 + other * 2.0   # a wave64 instruction occupies its SIMD-32 for 2 cycles, an FP64 one for 4

@@ -3,6 +3,7 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
+(cd $R && python3 -c "import bench; print(bench.kernel_sha())" > $OUT/kernel_sha.txt)  # the sources this profile is taken with
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras "$@" > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace exit $?"

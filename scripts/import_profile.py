@@ -34,6 +34,16 @@ for row in csv.DictReader(open(stats)):
 h = hashlib.sha256()
 for f in ("rtmi.hip", "rtmi_device.h"):
     h.update(open(os.path.join(ROOT, "raytrace_clj_amd", "csrc", f), "rb").read())
+sha = h.hexdigest()[:12]
+try:  # recorded on the GPU box when the profile was taken (scripts/gpu_prof.sh)
+    sha = open(os.path.join(src, "kernel_sha.txt")).read().strip() or sha
+except OSError:
+    pass
+launches_per_frame = 1
+try:
+    launches_per_frame = int(json.loads(open(bj).read().strip().splitlines()[-1])["roofline"]["launches_per_step"])
+except (OSError, ValueError, KeyError, IndexError):
+    pass
 fp64 = sum(m.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
 entry = {
     "valu_total": m["SQ_INSTS_VALU"], "valu_fp64": fp64, "salu_total": m.get("SQ_INSTS_SALU"), "vmem_total": m.get("SQ_INSTS_VMEM"),
@@ -41,7 +51,8 @@ entry = {
     "wave_time_share": {"issuing": round(m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"], 4), "waiting_for_issue": round(m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"], 4),
                         "in_s_waitcnt": round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 4)},
     "fetch_kb": m["FETCH_SIZE"], "write_kb": m["WRITE_SIZE"], "rocprof_avg_launch_ms": round(avg_ns / 1e6, 4),
-    "source": "profiles/%s_summary.txt" % name, "kernel_sha": h.hexdigest()[:12],
+    "launches_per_frame": launches_per_frame,
+    "source": "profiles/%s_summary.txt" % name, "kernel_sha": sha,
     "note": "rocprofv3 --pmc, one pass per counter group, mean per trace_kernel dispatch; FETCH_SIZE / WRITE_SIZE in KB, uncorrected (the kernel's "
             "reads are 32-byte node / scalar loads, not wide coalesced streams; the writes are 24-byte per-sample records)",
 }
