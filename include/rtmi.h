@@ -190,7 +190,9 @@ int rtmi_assemble_device(rtmi_ctx *ctx, int32_t nx, int32_t ny, int32_t world, i
  * device -- ncclGather on a communicator the library creates with ncclCommInitAll and owns (librccl is opened on first
  * use; a single-GPU host never loads it) -- and replica 0 un-tiles / quantises.  Pixels are independent and the stream key is
  * the global pixel index: the image is bit-identical to the single-device render.
- * Replicas that share a device (to rehearse the control flow on a one-GPU host) are gathered by device copies instead. */
+ * Replicas that share a device (to rehearse the control flow on a one-GPU host) are gathered by device copies instead, and so
+ * is a host on which librccl cannot be opened or initialised (one line on stderr; RTMI_MULTI_GATHER=rccl makes that an error,
+ * RTMI_MULTI_GATHER=copy forces the copies). */
 /* Replicates `scene` onto `ctx` (another device): the library copied the caller's arrays at creation. */
 int rtmi_scene_clone(rtmi_scene *scene, rtmi_ctx *ctx, rtmi_scene **out_scene);
 /* Replaces core.clj:100-108 on n devices.  scenes[r] = replica r (each on its own context).  Host buffers as rtmi_render

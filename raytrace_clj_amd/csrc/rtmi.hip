@@ -1733,6 +1733,7 @@ struct Rccl {
 };
 std::mutex g_multi_mu;
 Rccl g_rccl;
+bool g_rccl_failed = false; // RCCL could not be opened / initialised once: later gathers use peer copies
 std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms; // one communicator set per device list (ncclCommInitAll), kept for the process
 
 bool rccl_load() {
@@ -1790,18 +1791,28 @@ RTMI_EXPORT int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, i
         devs[(size_t)r] = scenes[r]->ctx->device;
         for (int q = 0; q < r; ++q) distinct = distinct && devs[(size_t)q] != devs[(size_t)r];
     }
-    const char *force = std::getenv("RTMI_MULTI_GATHER"); // "copy": never RCCL (diagnostics)
-    const bool use_rccl = n > 1 && distinct && !(force && !std::strcmp(force, "copy"));
+    const char *force = std::getenv("RTMI_MULTI_GATHER"); // "copy": never RCCL (diagnostics); "rccl": fail instead of falling back
+    bool use_rccl = n > 1 && distinct && !(force && !std::strcmp(force, "copy")) && !g_rccl_failed;
     std::vector<ncclComm_t> *comms = nullptr;
-    if (use_rccl) {
-        if (!rccl_load()) return fail(RTMI_E_DEVICE, "multi-device gather needs RCCL: %s", g_rccl.err.c_str());
-        auto it = g_comms.find(devs);
-        if (it == g_comms.end()) {
-            std::vector<ncclComm_t> cs((size_t)n);
-            NCCL_TRY(g_rccl.CommInitAll(cs.data(), n, devs.data()));
-            it = g_comms.emplace(devs, std::move(cs)).first;
+    if (use_rccl) { // the library owns its communicators: one set per device list, created on first use, kept for the process
+        std::string why;
+        if (!rccl_load()) why = g_rccl.err;
+        else {
+            auto it = g_comms.find(devs);
+            if (it == g_comms.end()) {
+                std::vector<ncclComm_t> cs((size_t)n);
+                const ncclResult_t e = g_rccl.CommInitAll(cs.data(), n, devs.data());
+                if (e != ncclSuccess) why = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(e);
+                else it = g_comms.emplace(devs, std::move(cs)).first;
+            }
+            if (why.empty()) comms = &it->second;
         }
-        comms = &it->second;
+        if (!why.empty()) { // no usable RCCL: the gather falls back to peer copies (same result, ordered with events), once and for all
+            if (force && !std::strcmp(force, "rccl")) return fail(RTMI_E_DEVICE, "multi-device gather: %s", why.c_str());
+            fprintf(stderr, "[rtmi] multi-device gather falls back to hipMemcpyPeerAsync: %s\n", why.c_str());
+            g_rccl_failed = true;
+            use_rccl = false;
+        }
     }
     // 1. every replica renders its tiles (r, r+n, ...) on its own device and stream, straight into its record
     HIP_TRY(hipSetDevice(c0->device));
