@@ -52,10 +52,12 @@ FP32_PEAK_TFLOPS = 157.3
 
 
 def kernel_sha():
-    """identifies the kernel sources a PMC profile was taken with"""
+    """identifies the DEVICE code a PMC profile was taken with: rtmi_device.h and the kernel section of rtmi.hip (everything above
+    the host-side C-ABI), so that host-only edits do not mark a profile stale"""
     h = hashlib.sha256()
-    for f in ("rtmi.hip", "rtmi_device.h"):
-        h.update(open(os.path.join(ROOT, "raytrace_clj_amd", "csrc", f), "rb").read())
+    d = os.path.join(ROOT, "raytrace_clj_amd", "csrc")
+    h.update(open(os.path.join(d, "rtmi_device.h"), "rb").read())
+    h.update(open(os.path.join(d, "rtmi.hip"), "rb").read().split(b"// host side: C-ABI")[0])
     return h.hexdigest()[:12]
 
 

@@ -31,10 +31,9 @@ avg_ns = None
 for row in csv.DictReader(open(stats)):
     if "trace_kernel" in row["Name"] and (avg_ns is None or int(row["Calls"]) > calls):
         avg_ns, calls = float(row["AverageNs"]), int(row["Calls"])
-h = hashlib.sha256()
-for f in ("rtmi.hip", "rtmi_device.h"):
-    h.update(open(os.path.join(ROOT, "raytrace_clj_amd", "csrc", f), "rb").read())
-sha = h.hexdigest()[:12]
+sys.path.insert(0, ROOT)
+import bench
+sha = bench.kernel_sha()
 try:  # recorded on the GPU box when the profile was taken (scripts/gpu_prof.sh)
     sha = open(os.path.join(src, "kernel_sha.txt")).read().strip() or sha
 except OSError:
