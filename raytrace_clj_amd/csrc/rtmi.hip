@@ -83,6 +83,9 @@ struct TraceParams {
 #ifndef RTMI_QUEUE_BLOCK
 #define RTMI_QUEUE_BLOCK 256
 #endif
+#ifndef RTMI_EXT_NO_STASH
+#define RTMI_EXT_NO_STASH 0 // 1: the EXT (f3 / f4) instantiations refill per trip (17 VGPRs fewer)
+#endif
 #ifndef RTMI_STASH
 #define RTMI_STASH 1 // camera rays generated 64 at a time at full wave width into a register stash (0: per trip, for the dead lanes only)
 #endif
@@ -218,12 +221,11 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
     bool alive = false;
     bool exhausted = (total_items == 0);
     unsigned out_item = 0; // work item of the lane's path: its colour goes to samples[out_item]
-#if RTMI_STASH
+    constexpr bool STASH = RTMI_STASH && !(EXT && RTMI_EXT_NO_STASH);
     R st_ox = R(0), st_oy = R(0), st_oz = R(0), st_dx = R(0), st_dy = R(0), st_dz = R(0), st_time = R(0); // the stash: one generated camera ray per lane
     u64 st_rs = 0;
     unsigned st_item = 0xffffffffu;
     unsigned s_head = 64u; // wave-uniform: entries [s_head, 64) are unclaimed
-#endif
     unsigned nrays = 0;
     unsigned ntrav[2] = {0u, 0u};
     const R tmin = R(0.001), tmax = Real<R>::tmax();
@@ -232,7 +234,7 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
     for (;;) {
         RTMI_STAMP(5) // loop overhead / tail
         // ---- refill dead lanes ------------------------------------------------------------------------------------------
-#if RTMI_STASH
+        if (STASH) {
         // Camera rays are generated 64 at a time by the WHOLE wave (key, jitter, lens disk loop, get-ray: start_sample at full
         // width) into a register stash, one entry per lane; dead lanes then pull entries across lanes (ds_bpermute): entry
         // s_head + (rank among the dead lanes).  Generating per trip for the dead lanes only ran start_sample at ~40 % width
@@ -285,7 +287,7 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
             }
             s_head += min(nd, avail);
         }
-#else
+        } else
         while (!exhausted) { // every lane of the wave takes part: the loop conditions are wave-uniform
             const u64 dead = __ballot(!alive);
             if (dead == 0) break;
@@ -316,7 +318,6 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
             }
             w_cur += min((unsigned)__popcll(dead), avail);
         }
-#endif
         if (MULTI) { if (!__syncthreads_or(alive ? 1 : 0)) break; }
         else { if (!__any(alive ? 1 : 0)) break; }
         RTMI_STAMP(0) // refill
