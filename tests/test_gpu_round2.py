@@ -84,6 +84,19 @@ def test_multi_device_entry_matches_single_device(cover11_moving):
         arr = (C.c_void_p * 2)(md.scenes[0].handle, md.scenes[0].handle)
         core.check(r._ffi.lib().rtmi_render_multi(2, arr, nx, ny, ns, 50, 1, 0, None, None, None))
     md.close()
+    one = rdist.MultiDevice(flat, [0])  # n = 1: no gather at all
+    olin, oq, ocnt = one.render(nx, ny, ns)
+    one.close()
+    assert np.array_equal(olin, lin) and np.array_equal(oq, q) and np.array_equal(ocnt, cnt)
+    # replicas must be clones of one scene
+    ctx_a, ctx_b = core.Context(0), core.Context(0)
+    sa, sb = core.DeviceScene(flat, ctx=ctx_a), core.DeviceScene(fl.flatten(r.scene.make_random_scene(200, 100, 3, False)), ctx=ctx_b)
+    import ctypes as C
+    arr = (C.c_void_p * 2)(sa.handle, sb.handle)
+    with pytest.raises(core.RtmiError) as e:
+        core.check(r._ffi.lib().rtmi_render_multi(2, arr, nx, ny, ns, 50, 1, 0, None, None, None))
+    assert e.value.code == -1
+    sb.close(); sa.close(); ctx_b.close(); ctx_a.close()
 
 
 def test_multi_device_entry_on_distinct_devices(cover11):
