@@ -371,6 +371,9 @@ def main():
         for k in ("aabb_tests_per_segment", "prim_tests_per_segment", "gather_ms"):
             if k in res:
                 out[k] = res[k]
+        if world > 1:
+            out["config"]["scaling_note"] = ("strong scaling of BASELINE configs[3] (the frame is fixed, its 8x8 tiles are dealt round-robin over the GPUs); the "
+                                             "N = 1 point of this curve is the 'c4' key of the `--gpus 1` line (same frame on one GPU), not that line's C3 value")
         if rehearsal:
             out["rehearsal"] = True
             out["config"]["workload"] += " -- REHEARSAL: the %d replicas share %d device(s); control flow only, not a measurement" % (world, visible)
