@@ -185,6 +185,8 @@ template <typename R> __device__ inline void rand_in_unit_sphere(Path<R> &P, R &
 // ("victims") get K = 64/n candidates each evaluated at once, one per lane: lane L takes candidate floor(L/n) of victim L mod n.
 // A victim takes its FIRST accepted candidate (util.clj:49-52: candidates are tried in order) and advances its stream past it,
 // i.e. by exactly the draws the sequential loop would have consumed; with no accepted candidate it advances by 3K and goes on.
+// kStrideMask[n] = sum over q < 64/n of 2^(q n)  (n = 1..64; scalar load, n is wave-uniform)
+__device__ __constant__ const unsigned long long kStrideMask[65] = {0ull, 0xffffffffffffffffull, 0x5555555555555555ull, 0x1249249249249249ull, 0x1111111111111111ull, 0x84210842108421ull, 0x41041041041041ull, 0x102040810204081ull, 0x101010101010101ull, 0x40201008040201ull, 0x4010040100401ull, 0x100200400801ull, 0x1001001001001ull, 0x8004002001ull, 0x40010004001ull, 0x200040008001ull, 0x1000100010001ull, 0x400020001ull, 0x1000040001ull, 0x4000080001ull, 0x10000100001ull, 0x40000200001ull, 0x400001ull, 0x800001ull, 0x1000001ull, 0x2000001ull, 0x4000001ull, 0x8000001ull, 0x10000001ull, 0x20000001ull, 0x40000001ull, 0x80000001ull, 0x100000001ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull, 0x1ull};
 #ifndef RTMI_COOP_SAMPLER
 #define RTMI_COOP_SAMPLER 1
 #endif
@@ -220,8 +222,7 @@ template <typename R> __device__ inline void rand_in_unit_sphere_wave(Path<R> &P
         const R cx = Real<R>::symmetric(mix64(rs_c + RTMI_GOLD)), cy = Real<R>::symmetric(mix64(rs_c + 2ull * RTMI_GOLD)),
                 cz = Real<R>::symmetric(mix64(rs_c + 3ull * RTMI_GOLD));
         const u64 acc = __ballot(c < K && !(dot3(cx, cy, cz, cx, cy, cz) >= R(1.0)));
-        u64 sm = 0; // the lanes that hold one victim's candidates, relative to its rank: 0, n, 2n, ...
-        for (int q = 0; q < K; ++q) sm |= 1ull << (q * n);
+        const u64 sm = kStrideMask[n]; // the lanes that hold one victim's candidates, relative to its rank: bits 0, n, 2n, ..., (K-1) n
         const u64 mine = pending ? ((acc >> vrank) & sm) : 0ull;
         const int first = mine ? __ffsll((long long)mine) - 1 : 0;
         const int src = mine ? vrank + first : lane;
