@@ -103,6 +103,99 @@ __device__ inline void substamp(int k) {
 #else
 #define RTMI_SUBSTAMP(k)
 #endif
+// FP64 square root.  The device libm's correctly rounded sqrt is v_rsq_f64 + nine fma/mul (Goldschmidt, two residual corrections)
+// wrapped in 14 more instructions: a 2^256 pre-scale for arguments below 2^-767 (whose residuals would underflow), the matching
+// post-scale and a v_cmp_class fix-up for 0 / inf.  When every active lane's argument is a finite number >= 2^-767 -- every
+// wave of a render; one integer compare on the high word and a wave-uniform branch decide -- the wrapper does nothing, and the
+// core sequence alone returns the same bits.  Any other wave takes the libm path.
+__device__ inline double rt_sqrt(double x) {
+    const unsigned hi = (unsigned)__double2hiint(x);
+    if (__ballot(hi - 0x10000000u >= 0x7ff00000u - 0x10000000u) != 0) return ::sqrt(x); // hi word of 2^-767 = 0x10000000
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = ::fma(-h, g, 0.5);
+    g = ::fma(g, r, g);
+    h = ::fma(h, r, h);
+    g = ::fma(::fma(-g, g, x), h, g);
+    g = ::fma(::fma(-g, g, x), h, g);
+    return g;
+}
+
+// FP64 atan2 / asin of the sphere uv (get-sphere-uv, hitable.clj:128-139: phi = atan2(z, x), theta = asin(y)).  The generic device libm spends two
+// v_mov per polynomial coefficient (a VALU FP64 instruction takes one literal-free scalar operand at most) -- ~75 of the ~280
+// instructions of the uv block.  Here the coefficients sit in a constant-memory table the wave reads with a few scalar loads and
+// the fma's take them as SGPR pairs.  atan2 divides ONCE: with a = min(|x|,|y|), b = max(|x|,|y|) the argument reduction about
+// 0.75 is (a - 0.75 b) / (b + 0.75 a) (two fma's), not (q - 0.75) / (1 + 0.75 q) of a quotient q = a / b.  Polynomials: the
+// fdlibm e_atan / e_asin minimax fits (11-term odd atan on |x| <= 7/16, 6/4 rational asin on t <= 1/4).  Both agree with a
+// host libm within 2 ulp (<= 4.5e-16 absolute) over the unit sphere -- they only feed texture coordinates.
+__device__ __constant__ double kTrig[32] = {
+    // [0..10] atan: aT0..aT10
+    3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01, -1.11111104054623557880e-01,
+    9.09088713343650656196e-02, -7.69187620504482999495e-02, 6.66107313738753120669e-02, -5.83357013379057348645e-02,
+    4.97687799461593236017e-02, -3.65315727442169155270e-02, 1.62858201153657823623e-02,
+    // [11,12] atan(0.75) hi, lo   [13,14] pi/2 hi, lo   [15,16] pi hi, lo
+    0x1.4978fa3269ee1p-1, 0x1.2419a87f2a458p-56, 1.57079632679489655800e+00, 6.12323399573676603587e-17, 3.1415926535897931160e+00,
+    1.2246467991473531772e-16,
+    // [17..22] asin: pS0..pS5   [23..26] qS1..qS4
+    1.66666666666666657415e-01, -3.25565818622400915405e-01, 2.01212532134862925881e-01, -4.00555345006794114027e-02,
+    7.91534994289814532176e-04, 3.47933107596021167570e-05, -2.40339491173441421878e+00, 2.02094576023350569471e+00,
+    -6.88283971605453293030e-01, 7.70381505559019352791e-02,
+    // [27] RN(1 / (2 pi))   [28] RN(1 / pi)   [29] 2 pi   [30] pi
+    0x1.45f306dc9c883p-3, 0x1.45f306dc9c883p-2, 6.283185307179586, 3.141592653589793, 0.0};
+// The table pointer passes through an empty asm so that the scalar loads stay next to their use: hoisted out of the path loop
+// (the whole kernel) the 54 SGPRs would be spilled to VGPR lanes and read back with one v_readlane per dword -- the v_mov's again.
+typedef const __attribute__((address_space(4))) double *TrigTable; // constant address space: scalar loads
+__device__ inline TrigTable trig_table() {
+    TrigTable K = (TrigTable)kTrig;
+    asm volatile("" : "+s"(K));
+    return K;
+}
+// a * b + c with c in an SGPR pair.  The compiler selects the two-address v_fmac (addend tied to the destination) and copies an
+// SGPR addend to VGPRs with two v_mov first; the three-address form takes it in place.
+__device__ inline double fma_s(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+__device__ inline double rt_atan2(double y, double x, TrigTable K) {
+    double c_hi = K[11], c_lo = K[12], h_hi = K[13], h_lo = K[14], p_hi = K[15], p_lo = K[16];
+    asm volatile("" : "+s"(c_hi), "+s"(c_lo), "+s"(h_hi), "+s"(h_lo), "+s"(p_hi), "+s"(p_lo)); // loaded here, not inside a branch
+    const double ax = ::fabs(x), ay = ::fabs(y);
+    const bool swap = ay > ax;
+    const double a = swap ? ax : ay, b = swap ? ay : ax;
+    const bool far = a > 0.4375 * b; // reduce about 0.75: |xr| <= 0.235 either way
+    const bool zero = b == 0.0;      // atan2(+-0, +-0)
+    double num = far ? ::fma(-0.75, b, a) : a, den = far ? ::fma(0.75, a, b) : b;
+    den = zero ? 1.0 : den;
+    const double xr = num / den, z = xr * xr, w = z * z;
+    const double s1 = z * fma_s(w, fma_s(w, fma_s(w, fma_s(w, ::fma(w, K[10], K[8]), K[6]), K[4]), K[2]), K[0]);
+    const double s2 = w * fma_s(w, fma_s(w, fma_s(w, ::fma(w, K[9], K[7]), K[5]), K[3]), K[1]);
+    const double hi = far ? c_hi : 0.0, lo = far ? c_lo : 0.0;
+    double r = hi - (::fma(xr, s1 + s2, -lo) - xr);
+    const double rs = h_hi - (r - h_lo);
+    r = swap ? rs : r;
+    const bool neg = (x < 0.0) | (zero & (bool)__builtin_signbit(x));
+    const double rn = p_hi - (r - p_lo);
+    r = neg ? rn : r;
+    return ::copysign(r, y);
+}
+__device__ inline double rt_asin(double x, TrigTable K) {
+    const double ax = ::fabs(x);
+    const bool small = ax < 0.5;
+    const double t = small ? x * x : ::fma(ax, -0.5, 0.5); // (1 - |x|) / 2, exact
+    const double p = t * fma_s(t, fma_s(t, fma_s(t, fma_s(t, ::fma(t, K[22], K[21]), K[20]), K[19]), K[18]), K[17]);
+    const double q = ::fma(t, fma_s(t, fma_s(t, ::fma(t, K[26], K[25]), K[24]), K[23]), 1.0);
+    const double r = p / q, s = rt_sqrt(t); // |x| > 1: t < 0, NaN like libm
+    const double big = K[13] - ::fma(2.0, ::fma(s, r, s), -K[14]);
+    return ::copysign(small ? ::fma(ax, r, ax) : big, x);
+}
+// x / c for a constant c with rc = RN(1 / c): q = RN(x rc) is within an ulp, r = x - c q is exact in one fma, and RN(q + r rc) is the
+// correctly rounded quotient (Markstein) -- the same value as the IEEE division the reference performs, in 3 instructions, not ~14
+__device__ inline double div_const(double x, double c, double rc) {
+    const double q = x * rc;
+    return ::fma(::fma(-c, q, x), rc, q);
+}
+
 template <typename R> struct Real;
 template <> struct Real<double> {
     // k = z >> 11 (53 bits) as a double: hi * 2^32 + lo in one fma (exact: k needs 53 bits), then k * 2^-53 (exact)
@@ -113,10 +206,16 @@ template <> struct Real<double> {
     __device__ static inline double symmetric(u64 z) { return ::fma(k53(z), 1.0 / 4503599627370496.0, -1.0); }
     __device__ static inline double tmax() { return 3.4028234663852886e38; } // Float/MAX_VALUE, core.clj:25
     __device__ static inline double pi() { return 3.141592653589793; }
-    __device__ static inline double sqrt_(double x) { return ::sqrt(x); }
+    __device__ static inline double sqrt_(double x) { return rt_sqrt(x); }
+    __device__ static inline double sqrt_lib(double x) { return ::sqrt(x); } // no wave-level branch: for loops the compiler unrolls
     __device__ static inline double sin_(double x) { return ::sin(x); }
-    __device__ static inline double asin_(double x) { return ::asin(x); }
-    __device__ static inline double atan2_(double y, double x) { return ::atan2(y, x); }
+    // get-sphere-uv (hitable.clj:128-139): u = 1 - (phi + pi) / (2 pi), v = (theta + pi/2) / pi; the two divisions by constants
+    // are the correctly rounded quotients (div_const)
+    __device__ static inline void sphere_uv(double nx, double ny, double nz, double *u, double *v) {
+        const TrigTable K = trig_table();
+        *u = 1.0 - div_const(rt_atan2(nz, nx, K) + K[30], K[29], K[27]);
+        *v = div_const(rt_asin(ny, K) + K[13], K[30], K[28]);
+    }
     __device__ static inline double pow_(double x, double y) { return ::pow(x, y); }
 };
 template <> struct Real<float> {
@@ -125,9 +224,12 @@ template <> struct Real<float> {
     __device__ static inline float tmax() { return 3.4028234663852886e38f; }
     __device__ static inline float pi() { return 3.141592653589793f; }
     __device__ static inline float sqrt_(float x) { return ::sqrtf(x); }
+    __device__ static inline float sqrt_lib(float x) { return ::sqrtf(x); }
     __device__ static inline float sin_(float x) { return ::sinf(x); }
-    __device__ static inline float asin_(float x) { return ::asinf(x); }
-    __device__ static inline float atan2_(float y, float x) { return ::atan2f(y, x); }
+    __device__ static inline void sphere_uv(float nx, float ny, float nz, float *u, float *v) {
+        *u = 1.0f - (::atan2f(nz, nx) + pi()) / (2.0f * pi());
+        *v = (::asinf(ny) + pi() / 2.0f) / pi();
+    }
     __device__ static inline float pow_(float x, float y) { return ::powf(x, y); }
 };
 
@@ -411,7 +513,7 @@ __device__ inline void scan_static(const Prim4<R> *__restrict__ lds, int n, int 
         const R c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - s.r2;
         const R disc = b * b - a4 * c;
         if (disc >= R(0)) {
-            const R sq = Real<R>::sqrt_(disc);
+            const R sq = Real<R>::sqrt_lib(disc);
             R t = (-b - sq) / a2;
             bool ok = (t > tmin) && (t < best_t);
             if (!ok) {
@@ -951,7 +1053,7 @@ __device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P
         double bq, cq, disc;
         sphere_test(s, L, a, bq, cq, disc);
         if (disc >= 0.0 && !(tmin >= 0.0 && bq > 0.0 && cq > 0.0)) {
-            const double sq = ::sqrt(disc);
+            const double sq = rt_sqrt(disc);
             double t = (-bq - sq) / a;
             if (!(t > tmin)) t = (-bq + sq) / a;
             if (t > tmin) ext_update(H, t, idx, false);
@@ -1005,7 +1107,7 @@ __device__ inline void ext_medium_test(SceneRef sc, int idx, Path<double> &P, do
     if (t1 < 0.0) t1 = 0.0;
     const int4 info = ext_ld_info<true>(sc.ext_info, idx);
     const LocalRay r = ext_local_ray<true>(sc, info.z, info.w, P);
-    const double mag = ::sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
+    const double mag = rt_sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
     const double dist_in = (t2 - t1) * mag;
     const double hit_distance = -(::log(next_uniform(P)) / density);
     if (hit_distance < dist_in) ext_update(H, t1 + hit_distance / mag, idx, true);
@@ -1113,11 +1215,7 @@ template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path
     h.nx = nx; h.ny = ny; h.nz = nz;
     h.u = R(0); h.v = R(0);
     if (h.kind == RTMI_PRIM_UVSPHERE && (all_uv || (kind_flags & RTMI_PRIM_NEEDS_UV))) {
-        const R PI = Real<R>::pi();
-        const R phi = Real<R>::atan2_(nz, nx);
-        const R theta = Real<R>::asin_(ny);
-        h.u = R(1.0) - (phi + PI) / (R(2.0) * PI);
-        h.v = (theta + PI / R(2.0)) / PI;
+        Real<R>::sphere_uv(nx, ny, nz, &h.u, &h.v);
     }
 }
 
@@ -1141,13 +1239,10 @@ __device__ inline void resolve_hit_ext(SceneRef sc, const Path<double> &P, doubl
             cx = g[0] * omf + g[4] * f; cy = g[1] * omf + g[5] * f; cz = g[2] * omf + g[6] * f;
         }
         nx = px - cx; ny = py - cy; nz = pz - cz;
-        const double len = ::sqrt(dot3(nx, ny, nz, nx, ny, nz));
+        const double len = rt_sqrt(dot3(nx, ny, nz, nx, ny, nz));
         if (len > 0.0) { const double inv = 1.0 / len; nx = nx * inv; ny = ny * inv; nz = nz * inv; }
         if (kind == RTMI_PRIM_UVSPHERE) {
-            const double PI = 3.141592653589793;
-            const double phi = ::atan2(nz, nx), theta = ::asin(ny);
-            h.u = 1.0 - (phi + PI) / (2.0 * PI);
-            h.v = (theta + PI / 2.0) / PI;
+            Real<double>::sphere_uv(nx, ny, nz, &h.u, &h.v);
         }
     } else if (kind == RTMI_PRIM_MEDIUM) { // hitable.clj:536-540: uv [0 0] and normal (1,0,0) are arbitrary
         nx = 1.0; ny = 0.0; nz = 0.0;
