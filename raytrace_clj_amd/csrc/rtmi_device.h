@@ -110,7 +110,7 @@ __device__ inline void substamp(int k) {
 // core sequence alone returns the same bits.  Any other wave takes the libm path.
 __device__ inline double rt_sqrt(double x) {
     const unsigned hi = (unsigned)__double2hiint(x);
-    if (__ballot(hi - 0x10000000u >= 0x7ff00000u - 0x10000000u) != 0) return ::sqrt(x); // hi word of 2^-767 = 0x10000000
+    if (__builtin_expect(__ballot(hi - 0x10000000u >= 0x7ff00000u - 0x10000000u) != 0, 0)) return ::sqrt(x); // hi word of 2^-767 = 0x10000000
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = y * 0.5;
     const double r = ::fma(-h, g, 0.5);
@@ -195,6 +195,44 @@ __device__ inline double div_const(double x, double c, double rc) {
     const double q = x * rc;
     return ::fma(::fma(-c, q, x), rc, q);
 }
+
+// t = n / a for the roots of one ray: a = d.d is the same for every sphere the ray meets (hitable.clj:186,192,200 divide by it per
+// root).  The IEEE division the compiler emits is: scale operands (v_div_scale x2), r = rcp(a) refined by two Newton steps
+// (4 fma), q = n r, e = n - a q, t = q + e r (v_div_fmas), special cases (v_div_fixup) -- 11 instructions + hazard nops, and the
+// scaling / fix-up only act on zero, infinite, NaN, denormal or far-apart operands.  Quot keeps the refined reciprocal of a per ray
+// and a root costs the last three operations, bit for bit the same quotient whenever the division would not have scaled, i.e.
+// for 2^-969 <= |n| < 2^568 when 2^-200 <= a <= 2^200.  Outside that range the quotients may differ, but then |t| < 2^-768 or
+// |t| >= 2^368 (or t is NaN where the division gives +-inf or 0): with 2^-300 <= t-min and best-so-far <= 2^200 either value fails
+// the same tests (t > t-min, t < best: hitable.clj:195,203), so nothing the scan keeps can differ.  `fast` is wave-uniform: one
+// lane with a outside [2^-200, 2^200] (or a t-min / t-max outside those bounds) sends the wave's ray segment to the plain division.
+template <typename R> struct Quot {
+    R a;
+    __device__ inline R operator()(R n) const { return n / a; }
+};
+template <> struct Quot<double> {
+    double a, r;
+    bool fast;
+    __device__ inline double operator()(double n) const {
+        if (__builtin_expect(!fast, 0)) return n / a;
+        const double q = n * r;
+        return ::fma(::fma(-a, q, n), r, q);
+    }
+};
+template <typename R> __device__ inline Quot<R> make_quot(R a, R, R) { return Quot<R>{a}; }
+template <> __device__ inline Quot<double> make_quot<double>(double a, double tmin, double tmax) {
+    Quot<double> q;
+    q.a = a;
+    const unsigned hi = (unsigned)__double2hiint(a);
+    q.fast = (__ballot(hi - (823u << 20) >= (400u << 20)) == 0) && tmin >= 0x1p-300 && tmax <= 0x1p200; // biased exponent in [823, 1223)
+    double r = __builtin_amdgcn_rcp(a);
+    r = ::fma(r, ::fma(-a, r, 1.0), r);
+    q.r = ::fma(r, ::fma(-a, r, 1.0), r);
+    return q;
+}
+template <typename R> __device__ inline R quot(R n, R a) { return n / a; }
+template <typename R> __device__ inline R quot(R n, const Quot<R> &a) { return a(n); }
+template <typename R> __device__ inline R coef(R a) { return a; }
+template <typename R> __device__ inline R coef(const Quot<R> &a) { return a.a; }
 
 template <typename R> struct Real;
 template <> struct Real<double> {
@@ -529,14 +567,14 @@ __device__ inline void scan_static(const Prim4<R> *__restrict__ lds, int n, int 
 // Exact early-out (only used when t-min >= 0): with the origin outside the sphere (c > 0) and the centre behind
 // the ray (b' = oc.d > 0) both roots are <= 0: -b'-sq < 0, and sq = sqrt(fl(fl(b'b') - fl(ac))) <= sqrt(fl(b'b')) = b'
 // (a correctly rounded sqrt of a correctly rounded square returns |x|), so -b'+sq <= 0: `t > t-min` fails for both.
-template <typename R>
-__device__ inline void sphere_roots(R bq, R cq, R disc, R a, R tmin, bool behind_ok, R &best_t, int &best_i, int idx) {
+template <typename R, typename A>
+__device__ inline void sphere_roots(R bq, R cq, R disc, const A &a, R tmin, bool behind_ok, R &best_t, int &best_i, int idx) {
     if (behind_ok && bq > R(0) && cq > R(0)) return;
     const R sq = Real<R>::sqrt_(disc);
-    R t = (-bq - sq) / a;
+    R t = quot<R>(-bq - sq, a);
     bool ok = (t > tmin) && (t < best_t);
     if (!ok) {
-        t = (-bq + sq) / a;
+        t = quot<R>(-bq + sq, a);
         ok = (t > tmin) && (t < best_t);
     }
     if (ok) { best_t = t; best_i = idx; }
@@ -676,8 +714,8 @@ __device__ inline float cull_disc(const CullGroup &G, int k, const CullRay &c) {
 
 // exact test of primitive i (original index; wave-uniform: scalar loads) for the lanes that survived the cull: Sphere /
 // UVSphere (hitable.clj:180-207 / 141-168) or MovingSphere (hitable.clj:219-252, centre = lerp(c0, c1, (time-t0)/(t1-t0)))
-template <typename R>
-__device__ inline void exact_prim_test(const double *exact12, int i, int idx, const Path<R> &P, R a, R tmin, bool behind_ok, R &best_t, int &best_i) {
+template <typename R, typename A>
+__device__ inline void exact_prim_test(const double *exact12, int i, int idx, const Path<R> &P, const A &a, R tmin, bool behind_ok, R &best_t, int &best_i) {
     typedef double d4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) d4 *cptr;
     const cptr p = (cptr)(exact12) + (size_t)i * 3;
@@ -693,8 +731,8 @@ __device__ inline void exact_prim_test(const double *exact12, int i, int idx, co
         s.cx = (R)q0.x * omf + (R)q1.x * f; s.cy = (R)q0.y * omf + (R)q1.y * f; s.cz = (R)q0.z * omf + (R)q1.z * f;
     }
     R bq, cq, disc;
-    sphere_test(s, P, a, bq, cq, disc);
-    if (disc >= R(0)) sphere_roots(bq, cq, disc, a, tmin, behind_ok, best_t, best_i, idx);
+    sphere_test(s, P, coef<R>(a), bq, cq, disc);
+    if (disc >= R(0)) sphere_roots<R>(bq, cq, disc, a, tmin, behind_ok, best_t, best_i, idx);
 }
 
 __device__ inline void cull_test_group(const CullGroup &G, int g, int last, const double *exact12, const Path<double> &P, const CullRay &c,
@@ -734,20 +772,20 @@ __device__ inline void scan_all_cull(SceneRef sc, const Path<double> &P, double 
 #define RTMI_BVH_STACK 32
 #endif
 
-template <typename R>
-__device__ inline void sphere_roots_any_order(R bq, R cq, R disc, R a, R tmin, bool behind_ok, R &best_t, int &best_i, int idx) {
+template <typename R, typename A>
+__device__ inline void sphere_roots_any_order(R bq, R cq, R disc, const A &a, R tmin, bool behind_ok, R &best_t, int &best_i, int idx) {
     if (behind_ok && bq > R(0) && cq > R(0)) return;
     const R sq = Real<R>::sqrt_(disc);
-    R t = (-bq - sq) / a;
-    if (!(t > tmin)) t = (-bq + sq) / a;
+    R t = quot<R>(-bq - sq, a);
+    if (!(t > tmin)) t = quot<R>(-bq + sq, a);
     if ((t > tmin) && ((t < best_t) || (t == best_t && idx < best_i))) { best_t = t; best_i = idx; }
 }
 
 // exact test of the primitive of leaf code `code` (per-lane: vector loads; a static sphere needs only its first 32 bytes).
 // RTMI_F32 reads the same FP64 records and rounds them to float exactly as the flat float scan does: centre (float)c,
 // r*r = one float multiply of (float)r (record slot 10), MovingSphere centre lerped in float.
-template <typename R>
-__device__ inline void exact_prim_test_lane(const double *exact12, int code, const Path<R> &P, R a, R tmin, bool behind_ok, R &best_t, int &best_i) {
+template <typename R, typename A>
+__device__ inline void exact_prim_test_lane(const double *exact12, int code, const Path<R> &P, const A &a, R tmin, bool behind_ok, R &best_t, int &best_i) {
     const int bits = ~code;
     const int idx = bits & 0x3fffffff;
     const double2 *g = reinterpret_cast<const double2 *>(exact12 + (size_t)idx * 12);
@@ -763,7 +801,7 @@ __device__ inline void exact_prim_test_lane(const double *exact12, int code, con
         s.cx = (R)g0.x * omf + (R)g2.x * f; s.cy = (R)g0.y * omf + (R)g2.y * f; s.cz = (R)g1.x * omf + (R)g3.x * f;
     }
     R bq, cq, disc;
-    sphere_test(s, P, a, bq, cq, disc);
+    sphere_test(s, P, coef<R>(a), bq, cq, disc);
     if (disc >= R(0)) sphere_roots_any_order<R>(bq, cq, disc, a, tmin, behind_ok, best_t, best_i, idx);
 }
 
@@ -940,14 +978,15 @@ __device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, 
     }
     // 1. the big primitives (sky dome, ground, ...): exact test, ascending Hitlist index
     if (COUNT) cnt[1] += (unsigned)sc.n_big;
-    for (int k = 0; k < sc.n_big; ++k) exact_prim_test<R>(exact12, sc.big_idx[k], sc.big_idx[k], P, a, tmin, behind_ok, best_t, best_i);
+    const Quot<R> qa = make_quot<R>(a, tmin, best_t); // every root of this ray divides by a
+    for (int k = 0; k < sc.n_big; ++k) exact_prim_test<R>(exact12, sc.big_idx[k], sc.big_idx[k], P, qa, tmin, behind_ok, best_t, best_i);
     // 2. the tree
-    auto leaf = [&](int code) { exact_prim_test_lane<R>(exact12, code, P, a, tmin, behind_ok, best_t, best_i); };
+    auto leaf = [&](int code) { exact_prim_test_lane<R>(exact12, code, P, qa, tmin, behind_ok, best_t, best_i); };
     auto best = [&]() { return (best_t < R(3.0e38) ? float_up((double)best_t) : 3.4028235e38f) + 0.0f; };
     bvh_traverse<COUNT>(sc, stack, r, leaf, best, cnt);
     // 3. a ray outside the shutter interval: the MovingSphere boxes were built for [t_lo, t_hi], so test every moving sphere exactly
     if (!r.time_ok)
-        for (int k = 0; k < sc.n_moving_all; ++k) exact_prim_test_lane<R>(exact12, ~(sc.moving_all[k] | 0x40000000), P, a, tmin, behind_ok, best_t, best_i);
+        for (int k = 0; k < sc.n_moving_all; ++k) exact_prim_test_lane<R>(exact12, ~(sc.moving_all[k] | 0x40000000), P, qa, tmin, behind_ok, best_t, best_i);
 }
 
 // ==== section 8(f3): RectXY/XZ/YZ (hitable.clj:269-363), Triangle (548-571), FlipNormals (375-381), Translate (391-396),
