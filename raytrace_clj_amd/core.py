@@ -208,6 +208,15 @@ def probe_arith(abc, ctx=None):
     return out
 
 
+def probe_math(abc, tmin=0.001, tmax=3.4028234663852886e38, ctx=None):
+    """[n, 8]: sqrt(a), atan2(a, b), asin(a), sphere u, v of (a, b, c), a / b by the per-ray reciprocal, a / (2 pi), reciprocal path taken"""
+    ctx = ctx or default_context()
+    abc = np.ascontiguousarray(abc, np.float64).reshape(-1, 3)
+    out = np.zeros((len(abc), 8))
+    check(_ffi.lib().rtmi_probe_math(ctx.handle, len(abc), ptr(abc), tmin, tmax, ptr(out)))
+    return out
+
+
 def sample_key(seed, pixel, sample):
     return int(_ffi.lib().rtmi_sample_key(seed, pixel, sample))
 

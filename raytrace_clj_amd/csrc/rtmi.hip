@@ -2108,6 +2108,24 @@ RTMI_EXPORT int rtmi_probe_rng(rtmi_ctx *c, int32_t precision, uint64_t key, uin
     return RTMI_OK;
 }
 
+// the path's own FP64 helpers (rtmi_device.h): square root with the wave-uniform fast path, the table-driven atan2 / asin and the uv
+// formula of get-sphere-uv, the per-ray reciprocal of the sphere roots, division by a constant
+__global__ void probe_math_kernel(int n, const double *abc, double tmin, double tmax, double *out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double a = abc[3 * k], b = abc[3 * k + 1], c = abc[3 * k + 2];
+    double *o = out + (size_t)k * 8;
+    o[0] = rt_sqrt(a);
+    const TrigTable K = trig_table();
+    o[1] = rt_atan2(a, b, K);
+    o[2] = rt_asin(a, K);
+    Real<double>::sphere_uv(a, b, c, &o[3], &o[4]);
+    const Quot<double> q = make_quot<double>(b, tmin, tmax);
+    o[5] = q(a);
+    o[6] = div_const(a, K[29], K[27]);
+    o[7] = (double)q.fast;
+}
+
 RTMI_EXPORT int rtmi_probe_arith(rtmi_ctx *c, int32_t n, const double *abc, double *out) {
     if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
     if (n <= 0 || !abc || !out) return fail(RTMI_E_ARG, "bad arguments");
@@ -2120,5 +2138,20 @@ RTMI_EXPORT int rtmi_probe_arith(rtmi_ctx *c, int32_t n, const double *abc, doub
     hipLaunchKernelGGL(probe_arith_kernel, dim3(grid), dim3(kBlock), 0, c->stream, n, d_in, d_out);
     PROBE_EPILOGUE()
     HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_probe_math(rtmi_ctx *c, int32_t n, const double *abc, double tmin, double tmax, double *out) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (n <= 0 || !abc || !out) return fail(RTMI_E_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    Tmp tmp;
+    double *d_in = (double *)tmp.up(abc, (size_t)n * 3 * sizeof(double));
+    double *d_out = (double *)tmp.alloc((size_t)n * 8 * sizeof(double));
+    if (!d_in || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(probe_math_kernel, dim3(grid), dim3(kBlock), 0, c->stream, n, d_in, tmin, tmax, d_out);
+    PROBE_EPILOGUE()
+    HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 8 * sizeof(double), hipMemcpyDeviceToHost));
     return RTMI_OK;
 }

@@ -70,6 +70,104 @@ def test_device_arithmetic_is_ieee():
     assert np.array_equal(out[:, 2], a * b + c), "a*b+c must not be contracted to an fma"
 
 
+def _ulp_gap(x, ref):
+    with np.errstate(invalid="ignore"):
+        return np.abs(x - ref) / np.spacing(np.abs(ref))
+
+
+def test_sqrt_fast_and_libm_paths_are_correctly_rounded():
+    """rt_sqrt: a wave whose arguments are all finite and >= 2^-767 takes the bare Goldschmidt core, any other wave the libm sequence;
+    both must return the correctly rounded root (= numpy's) -- waves of 64 consecutive probe threads are built to take each path"""
+    rng = np.random.default_rng(5)
+    n = 64 * 600
+    normal = np.abs(rng.normal(0, 1, n)) * 10.0 ** rng.integers(-12, 12, n) + 1e-300  # every wave: fast path
+    edge = np.array([2.0 ** -767, np.nextafter(2.0 ** -767, 1.0), 1.7976931348623157e308, 4.0, 2.0, 1.0 + 2 ** -52, 1e-200, 1e200] * 8)
+    specials = np.array([0.0, -0.0, np.inf, np.nan, -1.0, 5e-324, 2.2250738585072014e-308, np.nextafter(2.0 ** -767, 0.0)] * 8)
+    mixed = normal[: 64 * 100].copy()
+    mixed[::64] = np.resize(specials, 100)  # one lane per wave forces the libm path for the other 63 too
+    tiny = np.abs(rng.normal(0, 1, 64 * 50)) * 10.0 ** rng.integers(-320, -240, 64 * 50).astype(np.float64)
+    a = np.concatenate([normal, edge, mixed, specials, tiny])
+    abc = np.stack([a, np.ones_like(a), np.zeros_like(a)], axis=1)
+    out = core.probe_math(abc)[:, 0]
+    with np.errstate(invalid="ignore"):
+        ref = np.sqrt(a)
+    assert np.array_equal(out, ref, equal_nan=True)
+    assert np.array_equal(np.signbit(out), np.signbit(ref))
+
+
+def test_table_atan2_asin_against_libm():
+    """rt_atan2 / rt_asin (fdlibm fits, one division in atan2) feed only texture coordinates; bar: <= 2 ulp of the host libm, i.e. 4.5e-16 /
+    2.3e-16 absolute, and the special values of Math/atan2, Math/asin the uv formula can meet (poles, axes, |y| > 1 after normalise)"""
+    rng = np.random.default_rng(6)
+    v = rng.normal(0, 1, (200000, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v[::1000, 0] *= 1e-9
+    v[1::1000, 2] = 0.0
+    v[2::1000, 0] = 0.0
+    wide = np.stack([rng.normal(0, 1, 50000) * 10.0 ** rng.integers(-30, 30, 50000), rng.normal(0, 1, 50000) * 10.0 ** rng.integers(-30, 30, 50000),
+                     rng.uniform(-1, 1, 50000)], axis=1)
+    abc = np.concatenate([np.stack([v[:, 2], v[:, 0], v[:, 1]], axis=1), wide])
+    out = core.probe_math(abc)
+    ref = np.arctan2(abc[:, 0], abc[:, 1])
+    assert _ulp_gap(out[:, 1], ref).max() <= 2.0 and np.abs(out[:, 1] - ref).max() <= 4.5e-16
+    inside = np.abs(abc[:, 0]) <= 1.0
+    ref = np.arcsin(abc[inside, 0])
+    assert _ulp_gap(out[inside, 2], ref).max() <= 2.0 and np.abs(out[inside, 2] - ref).max() <= 2.3e-16
+    pi = np.pi
+    special = np.array([[0.0, 0.0, 0], [0.0, -0.0, 0], [-0.0, -0.0, 0], [-0.0, 0.0, 0], [0.0, 1.0, 0], [0.0, -1.0, 0], [1.0, 0.0, 0], [-1.0, 0.0, 0],
+                        [1.0, -0.0, 0], [1.0, 1.0, 0], [-1.0, -1.0, 0], [1e-320, 1e-320, 0], [-0.0, -1.0, 0], [0.5, 0, 0], [-0.5, 0, 0],
+                        [1.0000000000000002, 1.0, 0], [-1.0000000000000002, 1.0, 0]])
+    o = core.probe_math(special)
+    want = [0.0, pi, -pi, -0.0, 0.0, pi, pi / 2, -pi / 2, pi / 2, pi / 4, -3 * pi / 4, pi / 4, -pi]
+    assert list(o[:13, 1]) == want and list(np.signbit(o[:13, 1])) == [w < 0 or (w == 0 and np.signbit(w)) for w in want]
+    assert list(o[:4, 2]) == [0.0, 0.0, -0.0, -0.0] and list(np.signbit(o[:4, 2])) == [False, False, True, True]
+    assert o[6, 2] == pi / 2 and o[7, 2] == -pi / 2 and abs(o[13, 2] - np.arcsin(0.5)) <= 2.3e-16 and o[14, 2] == -o[13, 2]
+    assert np.isnan(o[15, 2]) and np.isnan(o[16, 2])  # Math/asin of |y| > 1 is NaN
+    # get-sphere-uv (hitable.clj:137-138) on top of them: the two divisions by constants are the correctly rounded quotients
+    n3 = np.stack([v[:, 0], v[:, 1], v[:, 2]], axis=1)
+    o = core.probe_math(n3)
+    phi, theta = np.arctan2(n3[:, 2], n3[:, 0]), np.arcsin(n3[:, 1])
+    assert np.abs(o[:, 3] - (1.0 - (phi + pi) / (2.0 * pi))).max() <= 1e-15 and np.abs(o[:, 4] - (theta + pi / 2.0) / pi).max() <= 1e-15
+    x = np.concatenate([rng.uniform(0, 2 * pi, 300000), np.nextafter(rng.uniform(0, 2 * pi, 100000), 10.0), [0.0, 2 * pi, pi, 5e-324, 1e-310]])
+    o = core.probe_math(np.stack([x, np.ones_like(x), np.zeros_like(x)], axis=1))
+    assert np.array_equal(o[:, 6], x / (2.0 * pi))
+
+
+def test_per_ray_reciprocal_division():
+    """Quot (the roots' t = n / a with the ray's refined reciprocal): the IEEE quotient bit for bit wherever the division would not scale its
+    operands, and -- for the numerators where it would -- a value that fails / passes t > t-min, t < best like the quotient does"""
+    rng = np.random.default_rng(7)
+    n = 64 * 400
+    a = np.abs(rng.normal(0, 1, n)) * 10.0 ** rng.integers(-6, 7, n) + 1e-12
+    num = rng.normal(0, 1, n) * 10.0 ** rng.integers(-12, 13, n)
+    o = core.probe_math(np.stack([num, a, np.zeros(n)], axis=1))
+    assert np.all(o[:, 7] == 1.0) and np.array_equal(o[:, 5], num / a)
+    # one lane with a out of range (or a t-min of 0, or an unbounded t-max) sends its whole wave to the plain division: same bits again
+    a2 = a.copy()
+    a2[::128] = np.resize([1e-80, 1e80, 0.0, np.inf, np.nan, 5e-324], len(a2[::128]))
+    o = core.probe_math(np.stack([num, a2, np.zeros(n)], axis=1))
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        ref = num / a2
+    flag = o[:, 7].reshape(-1, 64)
+    assert np.all(flag[::2] == 0.0) and np.all(flag[1::2] == 1.0) and np.array_equal(o[:, 5], ref, equal_nan=True)
+    for tmin, tmax in ((0.0, 3.4e38), (-1.0, 3.4e38), (0.001, np.inf), (0.001, 1e300)):
+        o = core.probe_math(np.stack([num, a, np.zeros(n)], axis=1), tmin=tmin, tmax=tmax)
+        assert np.all(o[:, 7] == 0.0) and np.array_equal(o[:, 5], num / a)
+    # numerators the division would scale (zero, denormal, tiny, huge, inf, NaN): same decisions
+    ext = np.resize(np.array([0.0, -0.0, 5e-324, -1e-310, 1e-300, -1e-295, 1e250, -1e290, 1.7e308, np.inf, -np.inf, np.nan]), n)
+    for tmin, tmax in ((0.001, 3.4028234663852886e38), (1e-80, 1e60)):
+        o = core.probe_math(np.stack([ext, a, np.zeros(n)], axis=1), tmin=tmin, tmax=tmax)
+        with np.errstate(invalid="ignore", over="ignore", under="ignore"):
+            ref = ext / a
+        assert np.all(o[:, 7] == 1.0)
+        keep = (ref > tmin) & (ref < tmax)
+        assert np.array_equal((o[:, 5] > tmin) & (o[:, 5] < tmax), keep) and np.array_equal(o[keep, 5], ref[keep])
+        # `t > t-min` alone (it decides whether the second root is looked at, hitable.clj:195-200) may differ only where the quotient
+        # is +inf / beyond any hit and the reciprocal form gives NaN: the second root is >= the first, so it is rejected as well
+        differs = (o[:, 5] > tmin) != (ref > tmin)
+        assert np.all(ref[differs] >= tmax) and np.all(np.isnan(o[differs, 5]))
+
+
 def test_rng_stream(oracle):
     cases = json.load(open(os.path.join(GOLD, "rng.json")))["cases"]
     for c in cases:
