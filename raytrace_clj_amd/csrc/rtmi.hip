@@ -77,6 +77,7 @@ struct TraceParams {
     unsigned *queue;       // work queue head of this pass (zeroed before the launch): next unclaimed work item
     unsigned total_items;  // n_local_tiles * s_count * 64
     unsigned qblock;       // work items a wave claims per queue access (a multiple of 64)
+    int suspend_lanes;     // time-sliced traversal: hand the wave back when fewer lanes than this are still in the tree (0: never)
     int rx0, ry0, rx1, ry1; // output region (row 0 = top): pixels outside it are not traced (whole frame: 0, 0, nx, ny)
     u64 *trav;             // COUNT instantiations: [0] += AABB slab tests (metrics aabb.intersection.total, hitable.clj:39), [1] += exact primitive tests
 };
@@ -138,15 +139,22 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
 }
 __device__ inline void intersect_ext(SceneRef, int *, bool, Path<float> &, bool, float, float tmax, float &best_t, int &best_i) { best_t = tmax; best_i = -1; }
 
-template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false>
+template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICED = false>
 __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, Path<R> &P,
-                                       bool active, R tmin, R tmax, R &best_t, int &best_i, unsigned *cnt = nullptr) {
+                                       bool active, R tmin, R tmax, R &best_t, int &best_i, unsigned *cnt = nullptr, bool *mid = nullptr, int min_lanes = 0) {
     if (EXT) { intersect_ext(sc, reinterpret_cast<int *>(lds), VARIANT == SCAN_BVH, P, active, tmin, tmax, best_t, best_i); return; }
     best_t = tmax;
     best_i = -1;
     const R a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
-    if (VARIANT == SCAN_BVH) { // RTMI_ACCEL_BVH; `lds` is the traversal stack
-        if (active) scan_bvh<R, COUNT>(sc, reinterpret_cast<int *>(lds), P, a, tmin, best_t, best_i, [&]() { scan_cull_dispatch(sc, P, a, tmin, best_t, best_i); }, cnt);
+    if (VARIANT == SCAN_BVH) { // RTMI_ACCEL_BVH; `lds` is the traversal stack, followed by the suspended lanes' state when the traversal is time-sliced
+        int *stack = reinterpret_cast<int *>(lds);
+        if (active) {
+            if (SLICED) {
+                const bool done = scan_bvh<R, COUNT, true>(sc, stack, P, a, tmin, best_t, best_i, [&]() { scan_cull_dispatch(sc, P, a, tmin, best_t, best_i); }, cnt,
+                                                           stack + RTMI_BVH_STACK * blockDim.x, *mid, min_lanes);
+                *mid = !done;
+            } else scan_bvh<R, COUNT>(sc, stack, P, a, tmin, best_t, best_i, [&]() { scan_cull_dispatch(sc, P, a, tmin, best_t, best_i); }, cnt);
+        }
         return;
     }
     if (VARIANT == SCAN_SGPR_CULL) { // all primitives, original order; returns the original index
@@ -229,6 +237,8 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
     unsigned nrays = 0;
     unsigned ntrav[2] = {0u, 0u};
     const R tmin = R(0.001), tmax = Real<R>::tmax();
+    constexpr bool SLICED = VARIANT == SCAN_BVH && !EXT && !MULTI;
+    bool mid = false; // this lane's segment is suspended inside the tree (SLICED)
 
     RTMI_STAMP_DECL
     for (;;) {
@@ -323,17 +333,25 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
         RTMI_STAMP(0) // refill
 
         // ---- one iteration of `color` for every live lane ---------------------------------------------
+        // SLICED (BVH kernels): the traversal hands the wave back as soon as fewer than tp.suspend_lanes lanes are still in the tree
+        // (a few rays of a wave visit ten times the nodes the others do: 40 % of the node-visit trips served < 8 lanes); those lanes
+        // are `mid` segment -- they sit out the shading below and resume where they stopped in the next trip, next to the new
+        // segments of the others.  Once the queue is empty nothing is gained by handing back early (suspend_lanes 0).
         R best_t; int best_i;
-        intersect_world<R, MULTI, VARIANT, EXT, COUNT>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i, ntrav);
+        intersect_world<R, MULTI, VARIANT, EXT, COUNT, SLICED>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i, ntrav,
+                                                               &mid, exhausted ? 0 : tp.suspend_lanes);
         RTMI_STAMP(1) // intersection
+        if (!SLICED || __any(alive && !mid)) { // a trip in which no lane finished its segment has nothing to shade
         if (alive) {
-            ++nrays;
+            if (!mid) ++nrays;
             R emit[3];
-            if (!shade_segment<R, EXT>(sc, P, best_t, best_i, nullptr, emit)) {
+            const bool scat = shade_segment<R, EXT>(sc, P, best_t, best_i, nullptr, emit, mid); // a `mid` lane is a passenger: it changes nothing
+            if (!mid && !scat) {
                 R *out = reinterpret_cast<R *>(tp.samples) + (size_t)out_item * 3;
                 out[0] = emit[0]; out[1] = emit[1]; out[2] = emit[2];
                 alive = false;
             }
+        }
         }
         RTMI_STAMP(2) // shading
     }
@@ -787,7 +805,9 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         const int variant = c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant;
         void (*kern)(ScenePtr, TraceParams) = nullptr;
         size_t dyn_lds = 0;
-        const size_t bvh_lds = (size_t)RTMI_BVH_STACK * kTraceBlock * sizeof(int);
+        const size_t bvh_lds = (size_t)(RTMI_BVH_STACK + RTMI_BVH_SUSPEND_WORDS) * kTraceBlock * sizeof(int); // stack columns + suspended cursors
+        tp.suspend_lanes = 8;
+        if (const char *e = std::getenv("RTMI_SUSPEND_LANES")) tp.suspend_lanes = std::max(0, std::min(64, std::atoi(e)));
         if (s->dev.has_ext) { // section 8(f3) scenes: FP64 kernels with the mixed-kind intersectors
             if (variant == SCAN_BVH) { kern = trace_kernel<double, false, SCAN_BVH, true>; dyn_lds = bvh_lds; }
             else kern = trace_kernel<double, false, SCAN_SGPR_CULL, true>;
@@ -1174,6 +1194,9 @@ RTMI_EXPORT int rtmi_shutdown(rtmi_ctx *c) {
     if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+#ifdef RTMI_HIST
+    { unsigned long long h[200]; if (hipMemcpyFromSymbol(h, HIP_SYMBOL(rtmi::g_hist), sizeof h) == hipSuccess) { for (int k = 0; k < 3; ++k) { fprintf(stderr, "HIST%d", k); for (int i = 0; i <= 64; ++i) fprintf(stderr, " %llu", h[64 * k + i]); fprintf(stderr, "\n"); } } }
+#endif
     c->samples.release(); c->accum.release(); c->tiles.release(); c->tile_ids.release(); c->counters.release(); c->scratch_lin.release(); c->multi.release();
     for (hipEvent_t e : {c->ev_done, c->ev_g0, c->ev_g1}) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

@@ -234,6 +234,9 @@ template <typename R> __device__ inline R quot(R n, const Quot<R> &a) { return a
 template <typename R> __device__ inline R coef(R a) { return a; }
 template <typename R> __device__ inline R coef(const Quot<R> &a) { return a.a; }
 
+#ifdef RTMI_HIST
+__device__ unsigned long long g_hist[200]; // diagnostic: [0..64] inner trips by active lanes, [64..128] leaf phases, [128..192] outer iterations
+#endif
 template <typename R> struct Real;
 template <> struct Real<double> {
     // k = z >> 11 (53 bits) as a double: hi * 2^32 + lo in one fma (exact: k needs 53 bits), then k * 2^-53 (exact)
@@ -897,20 +900,39 @@ __device__ inline unsigned long long stamp_now() {
     return t;
 }
 #endif
-template <bool NODE16, bool COUNT, typename Leaf, typename BestHi>
-__device__ inline void bvh_traverse_fmt(SceneRef sc, int *stack, const BvhRay &r, Leaf leaf, BestHi best, unsigned *cnt) {
-    int node = sc.bvh_root; // inner node: byte offset of its record (>= 0); leaf: ~(primitive | moving << 30) (< 0); RTMI_BVH_EMPTY: done
+// Where a lane's traversal stands: node = the node to visit next (inner node: byte offset of its record (>= 0); leaf: ~(primitive |
+// moving << 30) (< 0); RTMI_BVH_EMPTY: done), tos = the newest stack entry (a register), top = next free slot of the thread's LDS column.
+// The older entries live in the column; the bottom entry is a sentinel (RTMI_BVH_EMPTY, the initial tos), so popping needs no
+// emptiness test and the LDS read of a pop is only needed by the NEXT pop or push: its latency is off the critical path.  (The
+// tree's depth is < RTMI_BVH_STACK - 1 by construction; level 0 is only ever READ, by the pop of the sentinel.)
+struct BvhCursor { int node, tos; int *top; };
+__device__ inline BvhCursor bvh_cursor_at_root(SceneRef sc, int *stack) { return BvhCursor{sc.bvh_root, RTMI_BVH_EMPTY, stack + blockDim.x + threadIdx.x}; }
+
+// SLICE: TIME-SLICED traversal.  A few rays of a wave visit ten times the nodes the others do (C2: 42 % of the descent trips and 40 % of
+// the exact-test phases served fewer than 8 lanes, 20 % a single lane).  Two rules, one threshold: (1) the descent loop stops as soon
+// as fewer than min_lanes lanes are still descending -- the lanes that wait with a leaf get their exact test now, the stragglers
+// descend on in the next round, next to the lanes that have popped their next node; (2) the whole loop returns, with the cursors
+// of the unfinished lanes, as soon as fewer than min_lanes lanes still have nodes to visit (checked after each exact-test phase,
+// so every call makes progress): the caller lets the finished lanes move on and calls again with the same cursors and stack
+// columns.  Per lane the visiting order is the same depth-first order either way.  min_lanes = 0: plain while-while.
+template <bool NODE16, bool COUNT, bool SLICE, typename Leaf, typename BestHi>
+__device__ inline void bvh_traverse_fmt(SceneRef sc, const BvhRay &r, BvhCursor &cur, int min_lanes, Leaf leaf, BestHi best, unsigned *cnt) {
+    int node = cur.node;
     if (node == RTMI_BVH_EMPTY) return;
     const int stride = blockDim.x;
-    // The newest stack entry lives in a register (tos), the older ones in this thread's LDS column; the bottom entry is a sentinel
-    // (RTMI_BVH_EMPTY, the initial tos), so popping needs no emptiness test and the LDS read of a pop is only needed by the NEXT
-    // pop or push: its latency is off the critical path.  (The tree's depth is < RTMI_BVH_STACK - 1 by construction.)
-    int *top = stack + stride + threadIdx.x; // next free slot of this thread's column (level 0 is only ever READ, by the pop of the sentinel)
-    int tos = RTMI_BVH_EMPTY;
+    int *top = cur.top;
+    int tos = cur.tos;
     const char *nodes = reinterpret_cast<const char *>(sc.bvh_nodes);
     float best_hi = best();
     while (node != RTMI_BVH_EMPTY) {
-        while (node >= 0) { // inner node: both child boxes come with it (one record)
+#ifdef RTMI_HIST
+        { const int c = __popcll(__ballot(1)); if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_hist[128 + c], 1ull); }
+#endif
+        bool descend = node >= 0;
+        while (descend) { // inner node: both child boxes come with it (one record)
+#ifdef RTMI_HIST
+            { const int c = __popcll(__ballot(1)); if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_hist[c], 1ull); }
+#endif
             if (COUNT) cnt[0] += 2; // two AABB slab tests (the reference counts one per AABB.hit?, hitable.clj:39)
             float tl, tr;
             bool hl, hr;
@@ -947,46 +969,89 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, int *stack, const BvhRay &r
             } else if (hl) node = cl;
             else if (hr) node = cr;
             else { node = tos; top -= stride; tos = *top; } // pop (the sentinel ends the traversal)
+            descend = node >= 0;
+            // time-sliced: the few lanes on long descents stop holding up the lanes that wait with a leaf (one exit condition per lane:
+            // a wave-uniform `break` costs the structured loop a dozen scalar instructions per trip)
+            if (SLICE) descend = descend & (__popcll(__ballot(descend)) >= min_lanes);
         }
-        if (node != RTMI_BVH_EMPTY) { // leaf: one primitive, exact FP64 test
+        if (node < 0 && node != RTMI_BVH_EMPTY) { // leaf: one primitive, exact FP64 test
+#ifdef RTMI_HIST
+            { const int c = __popcll(__ballot(1)); if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_hist[64 + c], 1ull); }
+#endif
             if (COUNT) cnt[1] += 1;
             leaf(node);
             best_hi = best();
             node = tos; top -= stride; tos = *top;
         }
+        if (SLICE && __popcll(__ballot(node != RTMI_BVH_EMPTY)) < min_lanes) break; // wave-uniform
     }
+    cur.node = node; cur.tos = tos; cur.top = top;
 }
 
 // one loop per record format (a format test inside the loop costs 5 %)
-template <bool COUNT = false, typename Leaf, typename BestHi>
-__device__ inline void bvh_traverse(SceneRef sc, int *stack, const BvhRay &r, Leaf leaf, BestHi best, unsigned *cnt = nullptr) {
-    if (sc.bvh_node16) bvh_traverse_fmt<true, COUNT>(sc, stack, r, leaf, best, cnt);
-    else bvh_traverse_fmt<false, COUNT>(sc, stack, r, leaf, best, cnt);
+template <bool COUNT = false, bool SLICE = false, typename Leaf, typename BestHi>
+__device__ inline void bvh_traverse(SceneRef sc, const BvhRay &r, BvhCursor &cur, int min_lanes, Leaf leaf, BestHi best, unsigned *cnt = nullptr) {
+    if (sc.bvh_node16) bvh_traverse_fmt<true, COUNT, SLICE>(sc, r, cur, min_lanes, leaf, best, cnt);
+    else bvh_traverse_fmt<false, COUNT, SLICE>(sc, r, cur, min_lanes, leaf, best, cnt);
 }
+
+// what a suspended lane keeps between two calls of scan_bvh (time-sliced traversal): LDS, one column per thread like the stack
+#define RTMI_BVH_SUSPEND_WORDS 6 // node, tos, top (byte offset into the stack), best_t (2 words), best_i
+template <typename R> __device__ inline void best_to_words(R t, int &w0, int &w1);
+template <> __device__ inline void best_to_words<double>(double t, int &w0, int &w1) { w0 = __double2loint(t); w1 = __double2hiint(t); }
+template <> __device__ inline void best_to_words<float>(float t, int &w0, int &w1) { w0 = __float_as_int(t); w1 = 0; }
+template <typename R> __device__ inline R best_from_words(int w0, int w1);
+template <> __device__ inline double best_from_words<double>(int w0, int w1) { return __hiloint2double(w1, w0); }
+template <> __device__ inline float best_from_words<float>(int w0, int) { return __int_as_float(w0); }
 
 // flat(): the exact flat scan of the same precision, for rays the float boxes cannot bound
 // COUNT (diagnostic instantiation, RTMI option "count_traversal"): cnt[0] += AABB slab tests, cnt[1] += exact primitive tests
-template <typename R, bool COUNT = false, typename Flat>
-__device__ inline void scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, R tmin, R &best_t, int &best_i, Flat flat, unsigned *cnt = nullptr) {
+// Time-sliced use (susp != nullptr; min_lanes as in bvh_traverse_fmt): returns false when the lane's traversal was suspended -- its
+// cursor and closest hit so far are then in susp (RTMI_BVH_SUSPEND_WORDS columns of blockDim.x words) -- and the caller passes
+// resume = true on the next call with the SAME ray; best_t / best_i are only final when the function returns true.
+template <typename R, bool COUNT = false, bool SLICE = false, typename Flat>
+__device__ inline bool scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, R tmin, R &best_t, int &best_i, Flat flat, unsigned *cnt = nullptr,
+                                int *susp = nullptr, bool resume = false, int min_lanes = 0) {
     const bool behind_ok = tmin >= R(0);
     const double *exact12 = sc.exact12;
-    const BvhRay r = make_bvh_ray<R>(sc, P, a, tmin);
-    if (!r.ok) { // rays the float traversal cannot bound take the exact flat scan (all primitives, original order) instead
-        if (COUNT) cnt[1] += (unsigned)sc.n_all;
-        flat();
-        return;
+    const BvhRay r = make_bvh_ray<R>(sc, P, a, tmin); // a function of the ray: a resumed lane gets the values it had
+    const int stride = blockDim.x;
+    int *sw = susp + threadIdx.x;
+    BvhCursor cur;
+    if (SLICE && resume) {
+        cur.node = sw[0]; cur.tos = sw[stride];
+        cur.top = reinterpret_cast<int *>(reinterpret_cast<char *>(stack) + sw[2 * stride]);
+        best_t = best_from_words<R>(sw[3 * stride], sw[4 * stride]);
+        best_i = sw[5 * stride];
+    } else {
+        if (!r.ok) { // rays the float traversal cannot bound take the exact flat scan (all primitives, original order) instead
+            if (COUNT) cnt[1] += (unsigned)sc.n_all;
+            flat();
+            return true;
+        }
+        cur = bvh_cursor_at_root(sc, stack);
     }
-    // 1. the big primitives (sky dome, ground, ...): exact test, ascending Hitlist index
-    if (COUNT) cnt[1] += (unsigned)sc.n_big;
     const Quot<R> qa = make_quot<R>(a, tmin, best_t); // every root of this ray divides by a
-    for (int k = 0; k < sc.n_big; ++k) exact_prim_test<R>(exact12, sc.big_idx[k], sc.big_idx[k], P, qa, tmin, behind_ok, best_t, best_i);
+    if (!(SLICE && resume)) { // 1. the big primitives (sky dome, ground, ...): exact test, ascending Hitlist index
+        if (COUNT) cnt[1] += (unsigned)sc.n_big;
+        for (int k = 0; k < sc.n_big; ++k) exact_prim_test<R>(exact12, sc.big_idx[k], sc.big_idx[k], P, qa, tmin, behind_ok, best_t, best_i);
+    }
     // 2. the tree
     auto leaf = [&](int code) { exact_prim_test_lane<R>(exact12, code, P, qa, tmin, behind_ok, best_t, best_i); };
     auto best = [&]() { return (best_t < R(3.0e38) ? float_up((double)best_t) : 3.4028235e38f) + 0.0f; };
-    bvh_traverse<COUNT>(sc, stack, r, leaf, best, cnt);
+    bvh_traverse<COUNT, SLICE>(sc, r, cur, min_lanes, leaf, best, cnt);
+    if (SLICE && cur.node != RTMI_BVH_EMPTY) { // suspended
+        int w0, w1;
+        best_to_words<R>(best_t, w0, w1);
+        sw[0] = cur.node; sw[stride] = cur.tos;
+        sw[2 * stride] = (int)(reinterpret_cast<char *>(cur.top) - reinterpret_cast<char *>(stack));
+        sw[3 * stride] = w0; sw[4 * stride] = w1; sw[5 * stride] = best_i;
+        return false;
+    }
     // 3. a ray outside the shutter interval: the MovingSphere boxes were built for [t_lo, t_hi], so test every moving sphere exactly
     if (!r.time_ok)
         for (int k = 0; k < sc.n_moving_all; ++k) exact_prim_test_lane<R>(exact12, ~(sc.moving_all[k] | 0x40000000), P, qa, tmin, behind_ok, best_t, best_i);
+    return true;
 }
 
 // ==== section 8(f3): RectXY/XZ/YZ (hitable.clj:269-363), Triangle (548-571), FlipNormals (375-381), Translate (391-396),
@@ -1178,7 +1243,8 @@ __device__ inline void scan_bvh_ext(SceneRef sc, int *stack, const Path<double> 
     for (int k = 0; k < sc.n_big; ++k) ext_prim_test<true>(sc, sc.big_idx[k], P, tmin, H);
     auto leaf = [&](int code) { ext_prim_test<false>(sc, (~code) & 0x3fffffff, P, tmin, H); };
     auto best = [&]() { return ext_best_hi(H); };
-    bvh_traverse(sc, stack, r, leaf, best);
+    BvhCursor cur = bvh_cursor_at_root(sc, stack);
+    bvh_traverse(sc, r, cur, 0, leaf, best);
     if (!r.time_ok) // e.g. after Isotropic.scatter, which sets the ray's time to the hit's t (shader.clj:136)
         for (int k = 0; k < sc.n_moving_all; ++k) ext_prim_test<true>(sc, sc.moving_all[k], P, tmin, H);
 }
@@ -1317,7 +1383,7 @@ template <> __device__ inline void resolve_any<double, true>(SceneRef sc, const 
 // Returns true when the path continues (the `recur` of core.clj:30) with P holding the scattered ray.
 // `att` (optional) receives the attenuation of a successful scatter.  `emit` receives accum + atten * emitted of a path that
 // ends here (core.clj:37-39) with accum = (0 0 0): only a path's LAST segment can emit (the emitting Shader never scatters).
-template <typename R, bool F4 = false> __device__ inline bool scatter_emit(SceneRef sc, Path<R> &P, const HitRec<R> &h, R *att, R *emit) {
+template <typename R, bool F4 = false> __device__ inline bool scatter_emit(SceneRef sc, Path<R> &P, const HitRec<R> &h, R *att, R *emit, bool passenger = false) {
     // The material switch is laid out in PHASES shared by the materials that need them (one rejection-sampler loop,
     // one |d| normalisation, one texture evaluation per trip) instead of one inlined copy per material: the lanes of a
     // wave hold different materials, so every copy would be executed serially.  Per lane the operations and the draw
@@ -1328,8 +1394,8 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
     const int mk = (int)__double2loint(m0.x), mtex = (int)__double2hiint(m0.x), mtk = (int)__double2loint(m0.y);
     const R mparam = (R)m1.x;
     const R px = h.px, py = h.py, pz = h.pz, nx = h.nx, ny = h.ny, nz = h.nz;
-    const bool is_light = mk == RTMI_MAT_DIFFUSE_LIGHT;
-    const bool live = !is_light && P.depth > 0; // core.clj:27: (and (pos? depth) (scatter ...))
+    const bool is_light = !passenger && mk == RTMI_MAT_DIFFUSE_LIGHT;
+    const bool live = !passenger && !is_light && P.depth > 0; // core.clj:27: (and (pos? depth) (scatter ...))
     const bool is_lamb = live && mk == RTMI_MAT_LAMBERTIAN, is_metal = live && mk == RTMI_MAT_METAL, is_diel = live && mk == RTMI_MAT_DIELECTRIC;
     const bool is_iso = F4 && live && mk == RTMI_MAT_ISOTROPIC; // shader.clj:129-138, the phase function of ConstantMedium
     bool scat = false;
@@ -1416,14 +1482,17 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
 
 // One iteration of `color`'s loop after hit? has returned (core.clj:25-41).
 template <typename R, bool EXT = false>
-__device__ inline bool shade_segment(SceneRef sc, Path<R> &P, R t, int orig, SegLog *lg, R *emit) {
+// passenger: a lane with no hit to shade in this trip (its segment is suspended in the tree, see trace_kernel).  It stays in the wave
+// through scatter_emit -- the cooperative rand-in-unit-sphere wants all 64 lanes -- with every material flag off: P is untouched.
+__device__ inline bool shade_segment(SceneRef sc, Path<R> &P, R t, int orig, SegLog *lg, R *emit, bool passenger = false) {
     emit[0] = emit[1] = emit[2] = R(0);
-    if (orig < 0) return false; // miss: (color) returns accum, core.clj:40-41
+    if (!passenger && orig < 0) return false; // miss: (color) returns accum, core.clj:40-41
     HitRec<R> h;
+    h.px = h.py = h.pz = h.nx = h.ny = h.nz = h.u = h.v = h.t = R(0); h.mat = 0; h.orig = 0; h.kind = 0;
     RTMI_SUBSTAMP(-1)
-    resolve_any<R, EXT>(sc, P, t, orig, h, false);
+    if (!passenger) resolve_any<R, EXT>(sc, P, t, orig, h, false);
     RTMI_SUBSTAMP(8)
-    const bool scat = scatter_emit<R, EXT>(sc, P, h, nullptr, emit);
+    const bool scat = scatter_emit<R, EXT>(sc, P, h, nullptr, emit, passenger);
     if (lg && lg->n < lg->max_seg) {
         double *q = lg->rec + (size_t)lg->n * RTMI_SEG_REC;
         q[0] = h.orig; q[1] = h.t; q[2] = h.px; q[3] = h.py; q[4] = h.pz; q[5] = h.nx; q[6] = h.ny; q[7] = h.nz;
