@@ -1160,7 +1160,7 @@ int check_render_args(rtmi_scene *s, int nx, int ny, int ns, int depth, int prec
 // ---- library / context -------------------------------------------------------------------------------
 RTMI_EXPORT const char *rtmi_last_error(void) { return g_err.c_str(); }
 RTMI_EXPORT const char *rtmi_backend_name(void) { return "hip-gfx950"; }
-RTMI_EXPORT int rtmi_version(void) { return 200; }
+RTMI_EXPORT int rtmi_version(void) { return 201; }
 RTMI_EXPORT uint64_t rtmi_sample_key(uint64_t seed, uint64_t pixel, uint64_t sample) { return sample_key(seed, pixel, sample); }
 
 RTMI_EXPORT int rtmi_init(int device, uint32_t flags, rtmi_ctx **out_ctx) {
