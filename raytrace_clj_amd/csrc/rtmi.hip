@@ -645,6 +645,7 @@ struct rtmi_ctx {
     std::vector<int> tile_ids_host;
     int tile_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
     int count_traversal = 0;      // option "count_traversal": run the COUNT instantiation of the BVH kernels
+    int suspend_lanes = 8;        // option "suspend_lanes": threshold of the time-sliced BVH traversal (0 = plain while-while loop)
     hipStream_t last_stream = nullptr; // stream of the most recent render (rtmi_last_traversal_counters synchronises on it)
     long long tile_valid_pixels = 0;
     // timing
@@ -806,7 +807,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         void (*kern)(ScenePtr, TraceParams) = nullptr;
         size_t dyn_lds = 0;
         const size_t bvh_lds = (size_t)(RTMI_BVH_STACK + RTMI_BVH_SUSPEND_WORDS) * kTraceBlock * sizeof(int); // stack columns + suspended cursors
-        tp.suspend_lanes = 8;
+        tp.suspend_lanes = c->suspend_lanes;
         if (const char *e = std::getenv("RTMI_SUSPEND_LANES")) tp.suspend_lanes = std::max(0, std::min(64, std::atoi(e)));
         if (s->dev.has_ext) { // section 8(f3) scenes: FP64 kernels with the mixed-kind intersectors
             if (variant == SCAN_BVH) { kern = trace_kernel<double, false, SCAN_BVH, true>; dyn_lds = bvh_lds; }
@@ -1215,6 +1216,7 @@ RTMI_EXPORT int rtmi_set_option(rtmi_ctx *c, const char *name, int64_t value) {
     if (!std::strcmp(name, "timing")) { if (value) c->flags |= RTMI_FLAG_TIMING; else c->flags &= ~RTMI_FLAG_TIMING; return RTMI_OK; }
     if (!std::strcmp(name, "scan_variant")) { if (value < 0 || value > 3) return fail(RTMI_E_ARG, "scan_variant must be 0..3"); c->scan_variant = (int)value; return RTMI_OK; }
     if (!std::strcmp(name, "count_traversal")) { c->count_traversal = value ? 1 : 0; return RTMI_OK; }
+    if (!std::strcmp(name, "suspend_lanes")) { if (value < 0 || value > 64) return fail(RTMI_E_ARG, "suspend_lanes must be 0..64"); c->suspend_lanes = (int)value; return RTMI_OK; }
     if (!std::strcmp(name, "accel")) {
         if (value == RTMI_ACCEL_FLAT || value == RTMI_ACCEL_BVH) { c->accel = (int)value; return RTMI_OK; }
         return fail(RTMI_E_UNSUPPORTED, "accel %lld is not available in this build", (long long)value);

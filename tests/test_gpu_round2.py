@@ -308,3 +308,28 @@ def test_config_c4_frame_partitioned_over_8_ranks():
     mlin, mq, mcnt = md.render(nx, ny, ns)
     md.close()
     assert np.array_equal(mlin, base) and np.array_equal(mq, q) and np.array_equal(mcnt, cnt)
+
+
+def test_time_sliced_traversal_does_not_change_the_image():
+    """rtmi option "suspend_lanes": the threshold below which a wave's BVH traversal parks its last lanes (their cursor, stack column
+    and closest hit so far) and hands the wave back; per lane the visiting order is the same depth-first order, so every threshold --
+    0 = the plain while-while loop, 64 = hand back after every exact-test phase -- must give the same bits, counters included, in
+    both precisions and with moving spheres (whose out-of-shutter fallback runs after a resumed traversal too)"""
+    for moving, precision in ((False, "f64"), (True, "f64"), (False, "f32")):
+        scene = r.scene.make_random_scene(160, 80, 11, moving, mix=(0.6, 0.85))
+        flat = fl.flatten(scene)
+        ref = None
+        for lanes in (0, 1, 8, 33, 64):
+            ctx = core.Context(0)
+            ctx.set_option("suspend_lanes", lanes)
+            ctx.set_option("count_traversal", 1)
+            ds = core.DeviceScene(flat, ctx=ctx)
+            lin, q, cnt = ds.render(160, 80, 24, precision=precision)
+            trav = ctx.last_traversal_counters()
+            ds.close(); ctx.close()
+            if ref is None:
+                ref = (lin, q, cnt, trav)
+            else:
+                assert np.array_equal(lin, ref[0]) and np.array_equal(q, ref[1]) and list(cnt) == list(ref[2]) and trav == ref[3], (moving, precision, lanes)
+    with pytest.raises(core.RtmiError):
+        core.Context(0).set_option("suspend_lanes", 65)
