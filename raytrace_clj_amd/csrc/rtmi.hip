@@ -125,24 +125,32 @@ __device__ inline void scan_cull_dispatch(SceneRef sc, const Path<float> &P, flo
 // hit? of the whole world for the lane's ray (closest hit, t in (t-min, t-max); core.clj:25 passes 0.001, Float/MAX_VALUE).
 // MULTI (LDS variants only): the static spheres do not fit one LDS tile; every thread of the workgroup must call this.
 // section 8(f3) scenes (FP64 only): BVH or culled flat scan over mixed primitive kinds with the any-order tie rule
-__device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<double> &P, bool active, double tmin, double tmax, double &best_t, int &best_i) {
+template <bool SLICED = false>
+__device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<double> &P, bool active, double tmin, double tmax, double &best_t, int &best_i,
+                                     bool *mid = nullptr, int min_lanes = 0) {
     best_t = tmax; best_i = -1;
     if (!active) return;
     const double a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
     ExtHit H = {tmax, 0x7fffffff, -1, false};
-    if (bvh) scan_bvh_ext(sc, stack, P, a, tmin, H);
-    else scan_all_cull_ext(sc, P, a, tmin, H);
+    if (bvh) {
+        if (SLICED) { // time-sliced: a suspended lane's media are evaluated (and draw) when its traversal completes, as in the plain loop
+            const bool done = scan_bvh_ext<true>(sc, stack, P, a, tmin, H, stack + RTMI_BVH_STACK * blockDim.x, *mid, min_lanes);
+            *mid = !done;
+            if (!done) return;
+        } else scan_bvh_ext(sc, stack, P, a, tmin, H);
+    } else scan_all_cull_ext(sc, P, a, tmin, H);
     // media: after the surfaces, in primitive-index order = the order the reference's descent calls their hit? (and draws)
     for (int k = 0; k < sc.n_media; ++k) ext_medium_test(sc, sc.media_idx[k], P, tmin, tmax, H);
     best_i = ext_winner(H);
     if (best_i >= 0) best_t = H.t;
 }
-__device__ inline void intersect_ext(SceneRef, int *, bool, Path<float> &, bool, float, float tmax, float &best_t, int &best_i) { best_t = tmax; best_i = -1; }
+template <bool SLICED = false>
+__device__ inline void intersect_ext(SceneRef, int *, bool, Path<float> &, bool, float, float tmax, float &best_t, int &best_i, bool * = nullptr, int = 0) { best_t = tmax; best_i = -1; }
 
 template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICED = false>
 __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, Path<R> &P,
                                        bool active, R tmin, R tmax, R &best_t, int &best_i, unsigned *cnt = nullptr, bool *mid = nullptr, int min_lanes = 0) {
-    if (EXT) { intersect_ext(sc, reinterpret_cast<int *>(lds), VARIANT == SCAN_BVH, P, active, tmin, tmax, best_t, best_i); return; }
+    if (EXT) { intersect_ext<SLICED>(sc, reinterpret_cast<int *>(lds), VARIANT == SCAN_BVH, P, active, tmin, tmax, best_t, best_i, mid, min_lanes); return; }
     best_t = tmax;
     best_i = -1;
     const R a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
@@ -206,7 +214,8 @@ template <typename R> __device__ inline void start_sample(SceneRef sc, const Tra
     P.depth = tp.depth;
 }
 
-template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false>
+// SLICE: time-sliced BVH traversal (section 5.1b of DESIGN.md); the plain instantiation is kept for scenes whose tree is too small to gain
+template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICE = true>
 __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
     SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -237,7 +246,7 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
     unsigned nrays = 0;
     unsigned ntrav[2] = {0u, 0u};
     const R tmin = R(0.001), tmax = Real<R>::tmax();
-    constexpr bool SLICED = VARIANT == SCAN_BVH && !EXT && !MULTI;
+    constexpr bool SLICED = SLICE && VARIANT == SCAN_BVH && !MULTI;
     bool mid = false; // this lane's segment is suspended inside the tree (SLICED)
 
     RTMI_STAMP_DECL
@@ -660,6 +669,7 @@ struct rtmi_scene {
     ScenePtr d_dev = nullptr;   // the descriptor in HBM (what the kernels read)
     std::vector<void *> allocs;
     int n_prims = 0, n_mats = 0, n_tex = 0;
+    int bvh_node_count = 0;   // inner nodes of the device's tree
     bool uses_perlin = false; // a Perlin texture is present: rtmi_scene_set_perlin must have been called before rendering
     int max_image = -1;       // highest ImageMap index: rtmi_scene_set_images must cover it
     bool have_perlin = false;
@@ -810,11 +820,19 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         tp.suspend_lanes = c->suspend_lanes;
         if (const char *e = std::getenv("RTMI_SUSPEND_LANES")) tp.suspend_lanes = std::max(0, std::min(64, std::atoi(e)));
         if (s->dev.has_ext) { // section 8(f3) scenes: FP64 kernels with the mixed-kind intersectors
-            if (variant == SCAN_BVH) { kern = trace_kernel<double, false, SCAN_BVH, true>; dyn_lds = bvh_lds; }
+            if (variant == SCAN_BVH) { // a Cornell box's 20-primitive tree loses 5 % to the time-slicing machinery, make-final's 3400 gain 8 %
+                const bool slice = s->bvh_node_count >= 128 && tp.suspend_lanes > 0;
+                kern = slice ? trace_kernel<double, false, SCAN_BVH, true> : trace_kernel<double, false, SCAN_BVH, true, false, false>;
+                dyn_lds = (size_t)(RTMI_BVH_STACK + (slice ? RTMI_BVH_SUSPEND_WORDS_EXT : 0)) * kTraceBlock * sizeof(int);
+            }
             else kern = trace_kernel<double, false, SCAN_SGPR_CULL, true>;
         } else
         switch (variant) {
-        case SCAN_BVH: kern = c->count_traversal ? trace_kernel<R, false, SCAN_BVH, false, true> : trace_kernel<R, false, SCAN_BVH>; dyn_lds = bvh_lds; break;
+        case SCAN_BVH: // suspend_lanes = 0 selects the instantiation without the time-slicing machinery (the plain while-while loop)
+            if (tp.suspend_lanes > 0) kern = c->count_traversal ? trace_kernel<R, false, SCAN_BVH, false, true> : trace_kernel<R, false, SCAN_BVH>;
+            else kern = c->count_traversal ? trace_kernel<R, false, SCAN_BVH, false, true, false> : trace_kernel<R, false, SCAN_BVH, false, false, false>;
+            dyn_lds = bvh_lds;
+            break;
         case SCAN_SGPR_CULL: kern = trace_kernel<R, false, SCAN_SGPR_CULL>; break;
         case SCAN_SGPR: kern = trace_kernel<R, false, SCAN_SGPR>; break;
         case SCAN_LDS_PIPE: kern = multi ? trace_kernel<R, true, SCAN_LDS_PIPE> : trace_kernel<R, false, SCAN_LDS_PIPE>; dyn_lds = lds_bytes; break;
@@ -1464,6 +1482,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     for (int k = 0; k < n_media; ++k) d.media_idx[k] = media[k];
     s->host_kind = pk;
     const std::vector<float> bvh_nodes = build_bvh(d, n_world, pk.data(), wbox, bounded, cam);
+    s->bvh_node_count = (int)(bvh_nodes.size() / 16);
     if (!rc) rc = upload(s, bvh_nodes, &d.bvh_nodes);
     std::vector<int> moving_all;
     for (int i = 0; i < n_world; ++i) if (pk[(size_t)i] == RTMI_PRIM_MOVING) moving_all.push_back(i);

@@ -1237,16 +1237,39 @@ __device__ inline void scan_all_cull_ext(SceneRef sc, const Path<double> &P, dou
 
 __device__ inline float ext_best_hi(const ExtHit &H) { return (H.t < 3.0e38 ? float_up(H.t) : 3.4028235e38f) + 0.0f; }
 
-__device__ inline void scan_bvh_ext(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, ExtHit &H) {
+// Time-sliced like scan_bvh (susp: RTMI_BVH_SUSPEND_WORDS_EXT columns behind the stack; returns false when the lane's traversal was
+// suspended): the mixed-kind scenes need it most -- make-final's descent trips ran at 12.7 of 64 lanes, 66 % of them below 8.
+#define RTMI_BVH_SUSPEND_WORDS_EXT 7 // node, tos, top, H.t (2 words), H.F, H.W   (H.any <=> H.F != 0x7fffffff)
+template <bool SLICE = false>
+__device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, ExtHit &H, int *susp = nullptr, bool resume = false,
+                                    int min_lanes = 0) {
     const BvhRay r = make_bvh_ray(sc, P, a, tmin);
-    if (!r.ok) { scan_all_cull_ext(sc, P, a, tmin, H); return; }
-    for (int k = 0; k < sc.n_big; ++k) ext_prim_test<true>(sc, sc.big_idx[k], P, tmin, H);
+    const int stride = blockDim.x;
+    int *sw = susp + threadIdx.x;
+    BvhCursor cur;
+    if (SLICE && resume) {
+        cur.node = sw[0]; cur.tos = sw[stride];
+        cur.top = reinterpret_cast<int *>(reinterpret_cast<char *>(stack) + sw[2 * stride]);
+        H.t = __hiloint2double(sw[4 * stride], sw[3 * stride]);
+        H.F = sw[5 * stride]; H.W = sw[6 * stride]; H.any = H.F != 0x7fffffff;
+    } else {
+        if (!r.ok) { scan_all_cull_ext(sc, P, a, tmin, H); return true; }
+        for (int k = 0; k < sc.n_big; ++k) ext_prim_test<true>(sc, sc.big_idx[k], P, tmin, H);
+        cur = bvh_cursor_at_root(sc, stack);
+    }
     auto leaf = [&](int code) { ext_prim_test<false>(sc, (~code) & 0x3fffffff, P, tmin, H); };
     auto best = [&]() { return ext_best_hi(H); };
-    BvhCursor cur = bvh_cursor_at_root(sc, stack);
-    bvh_traverse(sc, r, cur, 0, leaf, best);
+    bvh_traverse<false, SLICE>(sc, r, cur, min_lanes, leaf, best);
+    if (SLICE && cur.node != RTMI_BVH_EMPTY) { // suspended
+        sw[0] = cur.node; sw[stride] = cur.tos;
+        sw[2 * stride] = (int)(reinterpret_cast<char *>(cur.top) - reinterpret_cast<char *>(stack));
+        sw[3 * stride] = __double2loint(H.t); sw[4 * stride] = __double2hiint(H.t);
+        sw[5 * stride] = H.any ? H.F : 0x7fffffff; sw[6 * stride] = H.W;
+        return false;
+    }
     if (!r.time_ok) // e.g. after Isotropic.scatter, which sets the ray's time to the hit's t (shader.clj:136)
         for (int k = 0; k < sc.n_moving_all; ++k) ext_prim_test<true>(sc, sc.moving_all[k], P, tmin, H);
+    return true;
 }
 
 // hitable.clj:219-252 (MovingSphere.hit?): centre = lerp(c0, c1, (time-t0)/(t1-t0)) per ray.
