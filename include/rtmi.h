@@ -98,7 +98,7 @@ int rtmi_shutdown(rtmi_ctx *ctx);
 /* knobs: "accel" (RTMI_ACCEL_*; default RTMI_ACCEL_BVH -- bit-identical to the flat scan), "count_traversal" (0/1: the next
  * renders run the counting instantiation of the BVH kernel, see rtmi_last_traversal_counters), "suspend_lanes" (0..64, default 8: the
  * BVH traversal of a wave stops descending / hands the wave back when fewer lanes than this are still descending / in the tree, and the
- * parked lanes resume in the next trip; 0 = the plain loop; the image does not depend on it), "workspace_bytes" (sample-buffer budget: a frame is rendered in as many sample passes as
+ * parked lanes resume in the next trip; 0 = the plain loop; the image does not depend on it), "workspace_bytes" (sample-buffer budget, default 64 GiB, allocated as needed: a frame is rendered in as many sample passes as
  * it takes), "blocks_per_cu" (cap on resident trace workgroups per CU; the launch never exceeds what stays resident),
  * "scan_variant" (flat scan: 0 LDS literal, 1 LDS pipelined, 2 scalar cache, 3 scalar cache + FP32 cull = default),
  * "lds_tile_bytes" (LDS variants), "timing" (0/1 = RTMI_FLAG_TIMING).

@@ -641,7 +641,7 @@ struct rtmi_ctx {
     size_t hbm = 0;
     std::string arch;
     int blocks_per_cu = 8; // workgroups per CU in the persistent grid (4 resident; the rest start as others drain: shorter tail)
-    int64_t workspace_bytes = (int64_t)16 << 30; // sample-buffer budget (HBM is 288 GB): 1920x1080x256 (12.7 GB of samples) renders in one pass
+    int64_t workspace_bytes = (int64_t)64 << 30; // sample-buffer budget (HBM is 288 GB; allocated as needed): 1920x1080x256 (12.7 GB of samples) renders in one pass, 3840x2160x512 in two
     int accel = RTMI_ACCEL_BVH; // bit-identical to the flat Hitlist scan and what every reference scene builds (scene.clj:332: make-bvh)
     int scan_variant = SCAN_SGPR_CULL;
     int max_lds_bytes = 64 * 1024 - 64; // static-sphere LDS tile budget per workgroup
