@@ -44,5 +44,27 @@ for node16 in ("1", "0"):
                         print("MISMATCH", name, prec, "node16", node16, "tmin", tmin, diff, "of", len(rays))
         print("ok" if not bad else "BAD", name, "node16=" + node16, "prims", f.n_prims, "hit fraction %.3f" % float((b[:, 0] == 1).mean()), flush=True)
         ds.close(); ctx.close()
-print("soak:", "PASS" if bad == 0 else "FAIL (%d rays differ)" % bad)
-sys.exit(1 if bad else 0)
+# Renders: the time-sliced traversal (suspend_lanes 8, 3, 40) against the plain while-while instantiation (0) and the flat scan, whole images
+# and counters, every scene, both node formats and precisions.
+rbad = 0
+for node16 in ("1", "0"):
+    os.environ["RTMI_NODE16"] = node16
+    for name, sc in scenes:
+        f = fl.flatten(sc)
+        for prec in ("f64", "f32"):
+            ref = None
+            for accel, lanes in ((0, 0), (1, 0), (1, 8), (1, 3), (1, 40)):
+                ctx = core.Context(0)
+                ctx.set_option("accel", accel)
+                ctx.set_option("suspend_lanes", lanes)
+                ds = core.DeviceScene(f, ctx=ctx)
+                out = ds.render(320, 160, 12, precision=prec)
+                ds.close(); ctx.close()
+                if ref is None:
+                    ref = out
+                elif not (np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1]) and list(out[2]) == list(ref[2])):
+                    rbad += 1
+                    print("RENDER MISMATCH", name, prec, "node16", node16, "accel", accel, "suspend_lanes", lanes)
+    print("renders ok" if not rbad else "renders BAD", "node16=" + node16, flush=True)
+print("soak:", "PASS" if bad == 0 and rbad == 0 else "FAIL (%d rays, %d renders differ)" % (bad, rbad))
+sys.exit(1 if bad or rbad else 0)
