@@ -265,6 +265,9 @@ def main():
         def trace_ms(self):
             return self.pl.last_trace_ms()
 
+        def reduce_ms(self):
+            return self.pl.last_reduce_ms()
+
         def counters(self):
             return int(self.tr.counters[0].item()), int(self.tr.counters[1].item())
 
@@ -295,6 +298,9 @@ def main():
             per = self.md.last_trace_ms()
             return per[0]  # replica 0's launches (the roofline prices one GPU's kernel)
 
+        def reduce_ms(self):
+            return self.md.ctxs[0].last_reduce_ms()
+
         def counters(self):
             self.md.sync()
             return int(self.cnt[0].item()), int(self.cnt[1].item())
@@ -319,6 +325,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         trace_ms, launches = drv.trace_ms()
+        reduce_ms, reduce_launches = drv.reduce_ms()
         gather_ms = drv.gather_ms() if world > 1 else None
         seg_local, pix_local = drv.counters()
         segments = seg_local
@@ -346,6 +353,14 @@ def main():
         res = {"value": round(samples / (dt / steps) / 1e6, 3), "ms_per_step": round(dt / steps * 1e3, 4), "segments": segments,
                "segments_per_sample": round(segments / samples, 4),
                "roofline": roofline(cfg_name, accel, args.precision, n_prims, launch_s, launches_per_step, counts, share=1.0 / world)}
+        if reduce_launches:  # the one HBM-bound kernel of the path: the in-order per-pixel sample reduction (core.clj:52-53)
+            red_s = reduce_ms / 1e3 / reduce_launches
+            red_bytes = (counts["samples"] * 24.0 + counts["pixels"] * 24.0 * (2 * launches_per_step - 1)) / launches_per_step  # samples read once; running sums written / re-read between passes
+            res["roofline"]["reduce_kernel"] = {"bound": "hbm", "achieved": round(red_bytes / red_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": round(red_bytes / red_s / 1e9 / HBM_PEAK_GBS, 4), "ms": round(red_s * 1e3, 4),
+                                                "bytes_per_launch": round(red_bytes), "share_of_step": round(reduce_ms / steps / (dt / steps * 1e3), 4),
+                                                "note": "reduce_kernel: one thread per pixel sums its samples in sample order (24 B each, coalesced 1536-B rows per tile and sample); "
+                                                        "duration = HIP events from the trace kernel's end to the reduction's end on the launch stream"}
         if count and accel == "bvh":
             res["aabb_tests_per_segment"] = round(counts["aabb_tests"] / max(1, counts["segments"]), 3)
             res["prim_tests_per_segment"] = round(counts["prim_tests"] / max(1, counts["segments"]), 3)

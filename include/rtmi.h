@@ -81,7 +81,7 @@ enum { RTMI_ACCEL_FLAT = 0, RTMI_ACCEL_BVH = 1 }; /* Hitlist scan (hitable.clj:1
 #define RTMI_TILE_PIXELS 64
 #define RTMI_SEG_REC 12      /* doubles per logged path segment: prim, t, p.xyz, n.xyz, next dir.xyz, scattered? */
 
-#define RTMI_FLAG_TIMING 1u  /* record HIP events around the trace kernel (rtmi_last_trace_ms) */
+#define RTMI_FLAG_TIMING 1u  /* record HIP events around the trace kernel and its reduction (rtmi_last_trace_ms, rtmi_last_reduce_ms) */
 
 typedef struct rtmi_ctx rtmi_ctx;
 typedef struct rtmi_scene rtmi_scene;
@@ -220,6 +220,9 @@ int rtmi_last_traversal_counters(rtmi_ctx *ctx, uint64_t *out_aabb_tests, uint64
  * (HIP events recorded on the launch stream around each launch; needs RTMI_FLAG_TIMING; synchronises on the
  * last event; at most 8192 launches are kept).  *launches = kernel launches covered.  Resets the window. */
 int rtmi_last_trace_ms(rtmi_ctx *ctx, double *ms, int32_t *launches);
+/* The in-order sample reductions (reduce_kernel, core.clj:52-53) of the measurement window the last rtmi_last_trace_ms call closed:
+ * sum of their durations (from each trace kernel's end event to the event after its reduction) and their number. */
+int rtmi_last_reduce_ms(rtmi_ctx *ctx, double *ms, int32_t *launches);
 
 /* ---- probes: the same device functions the render kernel runs, one protocol call at a time ---- */
 /* Hitable.hit? of the world for n rays {o.xyz, d.xyz, time}; out[n][11] = hit?, prim, t, p.xyz, normal.xyz, u, v */

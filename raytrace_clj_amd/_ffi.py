@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("RTMI_LIB") or os.path.join(_HERE, "lib", "librtmi.so"
 SYMBOLS = [
     "rtmi_last_error", "rtmi_backend_name", "rtmi_version", "rtmi_init", "rtmi_shutdown", "rtmi_set_option",
     "rtmi_device_info", "rtmi_scene_create", "rtmi_scene_create_ex", "rtmi_scene_set_perlin", "rtmi_scene_set_images", "rtmi_scene_set_media_calls", "rtmi_scene_destroy", "rtmi_render", "rtmi_render_device",
-    "rtmi_render_tiles_device", "rtmi_local_tiles", "rtmi_assemble_device", "rtmi_last_trace_ms", "rtmi_probe_hit",
+    "rtmi_render_tiles_device", "rtmi_local_tiles", "rtmi_assemble_device", "rtmi_last_trace_ms", "rtmi_last_reduce_ms", "rtmi_probe_hit",
     "rtmi_probe_paths", "rtmi_probe_camera", "rtmi_probe_texture", "rtmi_probe_scatter", "rtmi_probe_rng",
     "rtmi_sample_key", "rtmi_probe_arith", "rtmi_probe_math", "rtmi_last_traversal_counters",
     "rtmi_scene_clone", "rtmi_render_multi", "rtmi_render_multi_device", "rtmi_last_gather_ms",
@@ -73,6 +73,7 @@ def lib():
     L.rtmi_local_tiles.restype = i32
     L.rtmi_assemble_device.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp]
     L.rtmi_last_trace_ms.argtypes = [vp, C.POINTER(dbl), C.POINTER(i32)]
+    L.rtmi_last_reduce_ms.argtypes = [vp, C.POINTER(dbl), C.POINTER(i32)]
     L.rtmi_probe_hit.argtypes = [vp, i32, i32, vp, dbl, dbl, vp]
     L.rtmi_probe_paths.argtypes = [vp, i32, i32, vp, vp, u64, i32, vp, vp, vp, i32, vp]
     L.rtmi_probe_camera.argtypes = [vp, i32, i32, vp, vp, vp]

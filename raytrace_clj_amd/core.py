@@ -55,6 +55,12 @@ class Context:
         check(_ffi.lib().rtmi_last_trace_ms(self.handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def last_reduce_ms(self):
+        """(sum of reduce_kernel ms, launches) of the window the last last_trace_ms() call closed"""
+        ms, n = C.c_double(), C.c_int32()
+        check(_ffi.lib().rtmi_last_reduce_ms(self.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def last_traversal_counters(self):
         """(AABB slab tests, exact primitive tests) of the last render; needs set_option("count_traversal", 1) before it
         (metrics.clj:10 aabb.intersection.total, for the device's own tree)"""

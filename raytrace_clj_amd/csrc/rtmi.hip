@@ -653,6 +653,9 @@ struct rtmi_ctx {
     int last_grid = 0; // workgroups of the last trace launch (diagnostics)
     std::vector<int> tile_ids_host;
     int tile_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    std::vector<hipEvent_t> events_r; // RTMI_FLAG_TIMING: after the reduction that follows launch k
+    double last_reduce_ms = 0.0;      // of the window rtmi_last_trace_ms closed last
+    int last_reduce_launches = 0;
     int count_traversal = 0;      // option "count_traversal": run the COUNT instantiation of the BVH kernels
     int suspend_lanes = 8;        // option "suspend_lanes": threshold of the time-sliced BVH traversal (0 = plain while-while loop)
     hipStream_t last_stream = nullptr; // stream of the most recent render (rtmi_last_traversal_counters synchronises on it)
@@ -855,6 +858,11 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
                            reinterpret_cast<double *>(d_tiles_linear), reinterpret_cast<const int *>(c->tile_ids.p), tiles_x_of(nx), nx, ny,
                            n_local, s_begin, s_count, ns, d_counters ? cnt : nullptr, (u64)c->tile_valid_pixels, tp.rx0, tp.ry0, tp.rx1, tp.ry1);
         HIP_TRY(hipGetLastError());
+        if (e1) { // timing: the reduction is the interval from the trace kernel's end event to this one
+            const size_t k = (size_t)c->events_used - 1;
+            while (c->events_r.size() <= k) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->events_r.push_back(e); }
+            HIP_TRY(hipEventRecord(c->events_r[k], st));
+        }
     }
 #ifdef RTMI_STAMPS
     {
@@ -1179,7 +1187,7 @@ int check_render_args(rtmi_scene *s, int nx, int ny, int ns, int depth, int prec
 // ---- library / context -------------------------------------------------------------------------------
 RTMI_EXPORT const char *rtmi_last_error(void) { return g_err.c_str(); }
 RTMI_EXPORT const char *rtmi_backend_name(void) { return "hip-gfx950"; }
-RTMI_EXPORT int rtmi_version(void) { return 201; }
+RTMI_EXPORT int rtmi_version(void) { return 202; }
 RTMI_EXPORT uint64_t rtmi_sample_key(uint64_t seed, uint64_t pixel, uint64_t sample) { return sample_key(seed, pixel, sample); }
 
 RTMI_EXPORT int rtmi_init(int device, uint32_t flags, rtmi_ctx **out_ctx) {
@@ -1219,6 +1227,7 @@ RTMI_EXPORT int rtmi_shutdown(rtmi_ctx *c) {
     c->samples.release(); c->accum.release(); c->tiles.release(); c->tile_ids.release(); c->counters.release(); c->scratch_lin.release(); c->multi.release();
     for (hipEvent_t e : {c->ev_done, c->ev_g0, c->ev_g1}) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (hipEvent_t e : c->events_r) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     c->magic = 0;
     delete c;
@@ -1965,16 +1974,30 @@ RTMI_EXPORT int rtmi_last_traversal_counters(rtmi_ctx *c, uint64_t *out_aabb_tes
 RTMI_EXPORT int rtmi_last_trace_ms(rtmi_ctx *c, double *ms, int32_t *launches) {
     if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
     if (!(c->flags & RTMI_FLAG_TIMING)) return fail(RTMI_E_STATE, "context was not created with RTMI_FLAG_TIMING");
-    double total = 0.0;
+    double total = 0.0, reduce = 0.0;
     for (int k = 0; k < c->events_used; ++k) {
         HIP_TRY(hipEventSynchronize(c->events[(size_t)k].second));
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, c->events[(size_t)k].first, c->events[(size_t)k].second));
         total += t;
+        if ((size_t)k < c->events_r.size()) {
+            HIP_TRY(hipEventSynchronize(c->events_r[(size_t)k]));
+            HIP_TRY(hipEventElapsedTime(&t, c->events[(size_t)k].second, c->events_r[(size_t)k]));
+            reduce += t;
+        }
     }
     if (ms) *ms = total;
     if (launches) *launches = c->events_used;
+    c->last_reduce_ms = reduce; c->last_reduce_launches = c->events_used;
     c->events_used = 0; // the next render starts a new measurement window
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_last_reduce_ms(rtmi_ctx *c, double *ms, int32_t *launches) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (!(c->flags & RTMI_FLAG_TIMING)) return fail(RTMI_E_STATE, "context was not created with RTMI_FLAG_TIMING");
+    if (ms) *ms = c->last_reduce_ms;
+    if (launches) *launches = c->last_reduce_launches;
     return RTMI_OK;
 }
 

@@ -208,6 +208,14 @@ class FramePipeline:
             ms, n = ms + a, n + b
         return ms, n
 
+    def last_reduce_ms(self):
+        """(sum of reduce_kernel durations in ms, launches) of the window the last last_trace_ms() closed"""
+        ms, n = 0.0, 0
+        for ctx, _, _, _ in self.slots:
+            a, b = ctx.last_reduce_ms()
+            ms, n = ms + a, n + b
+        return ms, n
+
     def close(self):
         for ctx, ds, _, _ in self.slots:
             ds.close()
