@@ -382,29 +382,37 @@ __global__ void __launch_bounds__(kBlock) reduce_kernel(const R *__restrict__ sa
                                                         const int *__restrict__ tile_ids, int tiles_x, int nx, int ny, int n_local_tiles,
                                                         int s_begin, int s_count, int ns, u64 *counters, u64 n_valid_pixels,
                                                         int rx0, int ry0, int rx1, int ry1) {
+    // A (tile, sample) row is 64 pixels x 3 channels = 192 consecutive values; the sum over the samples is element-wise, so lane l of the
+    // tile's wave owns elements l, l + 64, l + 128 of the row (pixel j / 3, channel j % 3): every load of the wave is one contiguous
+    // 64-element run (a thread per PIXEL read its 3 values at a 24-byte stride, three passes over the same cache lines).  Per element
+    // the additions are still s = 0, 1, 2, ... in order.
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid == 0 && counters && s_begin + s_count >= ns) counters[1] = n_valid_pixels; // metrics total-pixels, core.clj:47
     if (gid >= (long long)n_local_tiles * 64) return;
     const int tile_local = (int)(gid >> 6), l = (int)(gid & 63);
     const int gtile = tile_ids[tile_local];
-    const int x = (gtile % tiles_x) * RTMI_TILE + (l & 7), y = (gtile / tiles_x) * RTMI_TILE + (l >> 3);
-    const bool valid = x >= rx0 && x < rx1 && y >= ry0 && y < ry1;
-    R r = R(0), g = R(0), b = R(0);
-    if (valid) {
-        if (s_begin > 0) { r = accum[gid * 3]; g = accum[gid * 3 + 1]; b = accum[gid * 3 + 2]; }
-        for (int s = 0; s < s_count; ++s) {
-            const R *p = samples + (((size_t)tile_local * s_count + s) * 64 + l) * 3;
-            if (s_begin + s == 0) { r = p[0]; g = p[1]; b = p[2]; }
-            else { r = r + p[0]; g = g + p[1]; b = b + p[2]; }
-        }
+    const int tx = (gtile % tiles_x) * RTMI_TILE, ty = (gtile / tiles_x) * RTMI_TILE;
+    R acc[3];
+    bool valid[3];
+    const size_t tile_base = (size_t)tile_local * 192;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int p = (l + 64 * k) / 3; // pixel of the tile this element belongs to
+        const int x = tx + (p & 7), y = ty + (p >> 3);
+        valid[k] = x >= rx0 && x < rx1 && y >= ry0 && y < ry1;
+        acc[k] = (valid[k] && s_begin > 0) ? accum[tile_base + l + 64 * k] : R(0);
     }
-    if (s_begin + s_count < ns) {
-        accum[gid * 3] = r; accum[gid * 3 + 1] = g; accum[gid * 3 + 2] = b;
-    } else {
-        const R inv = R(1.0) / (R)ns;
-        tiles_linear[gid * 3] = valid ? (double)(r * inv) : 0.0;
-        tiles_linear[gid * 3 + 1] = valid ? (double)(g * inv) : 0.0;
-        tiles_linear[gid * 3 + 2] = valid ? (double)(b * inv) : 0.0;
+    const R *row = samples + (size_t)tile_local * s_count * 192 + l;
+    for (int s = 0; s < s_count; ++s, row += 192) {
+        const R v0 = row[0], v1 = row[64], v2 = row[128];
+        if (s_begin + s == 0) { acc[0] = v0; acc[1] = v1; acc[2] = v2; } // the fold starts FROM the first sample (not 0 + first)
+        else { acc[0] = acc[0] + v0; acc[1] = acc[1] + v1; acc[2] = acc[2] + v2; }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const size_t o = tile_base + l + 64 * k;
+        if (s_begin + s_count < ns) accum[o] = valid[k] ? acc[k] : R(0);
+        else tiles_linear[o] = valid[k] ? (double)(acc[k] * (R(1.0) / (R)ns)) : 0.0;
     }
 }
 
