@@ -333,3 +333,25 @@ def test_time_sliced_traversal_does_not_change_the_image():
                 assert np.array_equal(lin, ref[0]) and np.array_equal(q, ref[1]) and list(cnt) == list(ref[2]) and trav == ref[3], (moving, precision, lanes)
     with pytest.raises(core.RtmiError):
         core.Context(0).set_option("suspend_lanes", 65)
+
+
+def test_reduce_timing_window():
+    """rtmi_last_reduce_ms reports the in-order sample reductions of the window rtmi_last_trace_ms closed: one per trace launch (several when
+    the sample buffer forces passes), each a positive duration well below the trace kernel's"""
+    scene = r.scene.make_random_scene(320, 160, 11, False)
+    ctx = core.Context(0, timing=True)
+    ds = core.DeviceScene(fl.flatten(scene), ctx=ctx)
+    ds.render(320, 160, 32)
+    t_ms, t_n = ctx.last_trace_ms()
+    r_ms, r_n = ctx.last_reduce_ms()
+    assert t_n == 1 and r_n == 1 and 0.0 < r_ms < t_ms
+    ctx.set_option("workspace_bytes", 4 << 20)  # 320 x 160 x 24 B = 1.2 MB per sample: 3 samples per pass
+    ds.render(320, 160, 32)
+    t_ms, t_n = ctx.last_trace_ms()
+    r_ms, r_n = ctx.last_reduce_ms()
+    assert t_n == r_n == 11 and 0.0 < r_ms < t_ms
+    ds.close(); ctx.close()
+    plain = core.Context(0)
+    with pytest.raises(core.RtmiError):
+        plain.last_reduce_ms()
+    plain.close()
