@@ -1499,7 +1499,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     for (int k = 0; k < n_media; ++k) d.media_idx[k] = media[k];
     s->host_kind = pk;
     const std::vector<float> bvh_nodes = build_bvh(d, n_world, pk.data(), wbox, bounded, cam);
-    s->bvh_node_count = (int)(bvh_nodes.size() / 16);
+    s->bvh_node_count = (int)(bvh_nodes.size() / (d.bvh_node16 ? 8 : 16));
     if (!rc) rc = upload(s, bvh_nodes, &d.bvh_nodes);
     std::vector<int> moving_all;
     for (int i = 0; i < n_world; ++i) if (pk[(size_t)i] == RTMI_PRIM_MOVING) moving_all.push_back(i);
