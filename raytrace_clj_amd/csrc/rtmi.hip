@@ -839,8 +839,8 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             else kern = trace_kernel<double, false, SCAN_SGPR_CULL, true>;
         } else
         switch (variant) {
-        case SCAN_BVH: // suspend_lanes = 0 selects the instantiation without the time-slicing machinery (the plain while-while loop)
-            if (tp.suspend_lanes > 0) kern = c->count_traversal ? trace_kernel<R, false, SCAN_BVH, false, true> : trace_kernel<R, false, SCAN_BVH>;
+        case SCAN_BVH: // suspend_lanes = 0 or a small tree (< 128 inner nodes) selects the instantiation without the time-slicing machinery (the plain while-while loop)
+            if (tp.suspend_lanes > 0 && s->bvh_node_count >= 128) kern = c->count_traversal ? trace_kernel<R, false, SCAN_BVH, false, true> : trace_kernel<R, false, SCAN_BVH>;
             else kern = c->count_traversal ? trace_kernel<R, false, SCAN_BVH, false, true, false> : trace_kernel<R, false, SCAN_BVH, false, false, false>;
             dyn_lds = bvh_lds;
             break;
