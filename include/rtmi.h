@@ -101,7 +101,8 @@ int rtmi_shutdown(rtmi_ctx *ctx);
  * parked lanes resume in the next trip; 0 = the plain loop; the image does not depend on it), "workspace_bytes" (sample-buffer budget, default 64 GiB, allocated as needed: a frame is rendered in as many sample passes as
  * it takes), "blocks_per_cu" (cap on resident trace workgroups per CU; the launch never exceeds what stays resident),
  * "scan_variant" (flat scan: 0 LDS literal, 1 LDS pipelined, 2 scalar cache, 3 scalar cache + FP32 cull = default),
- * "lds_tile_bytes" (LDS variants), "timing" (0/1 = RTMI_FLAG_TIMING).
+ * "lds_tile_bytes" (LDS variants), "timing" (0/1 = RTMI_FLAG_TIMING); test hooks: "test_fail_next_render" (the context's next render
+ * fails before launching anything), "test_fail_allocs" (its next n sample-buffer allocations fail).
  * A context owns its workspace and work queue and is not re-entrant; for several frames in flight on one GPU use one context
  * (and one stream) per frame slot. */
 int rtmi_set_option(rtmi_ctx *ctx, const char *name, int64_t value);
@@ -193,8 +194,12 @@ int rtmi_assemble_device(rtmi_ctx *ctx, int32_t nx, int32_t ny, int32_t world, i
  * use; a single-GPU host never loads it) -- and replica 0 un-tiles / quantises.  Pixels are independent and the stream key is
  * the global pixel index: the image is bit-identical to the single-device render.
  * Replicas that share a device (to rehearse the control flow on a one-GPU host) are gathered by device copies instead, and so
- * is a host on which librccl cannot be opened or initialised (one line on stderr; RTMI_MULTI_GATHER=rccl makes that an error,
- * RTMI_MULTI_GATHER=copy forces the copies). */
+ * is a host on which librccl cannot be opened or initialised, or whose gather failed once (one line on stderr).
+ * RTMI_MULTI_GATHER=rccl: RCCL or an error, never a substitution -- and a ONE-replica call then goes through the whole RCCL path too
+ * (dlopen, ncclCommInitAll of one rank, grouped in-place ncclGather): that is how the path is executed on a one-GPU host (status:
+ * the one-rank path runs in the GPU test suite; a communicator over several devices has not run yet -- no multi-GPU host so far).
+ * RTMI_MULTI_GATHER=copy forces the copies.  rtmi_last_gather_path says which one ran.
+ * On an error after the first replica's launch every replica stream touched so far is synchronised before the call returns. */
 /* Replicates `scene` onto `ctx` (another device): the library copied the caller's arrays at creation. */
 int rtmi_scene_clone(rtmi_scene *scene, rtmi_ctx *ctx, rtmi_scene **out_scene);
 /* Replaces core.clj:100-108 on n devices.  scenes[r] = replica r (each on its own context).  Host buffers as rtmi_render
@@ -205,6 +210,22 @@ int rtmi_render_multi(int32_t n, rtmi_scene *const *scenes, int32_t nx, int32_t 
  * renders on its own context stream). */
 int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed,
                              int32_t precision, void *d_out_linear, void *d_out_rgb8, void *d_out_counters);
+/* How the last rtmi_render_multi* on replica 0's context moved the replicas' records to replica 0's device. */
+enum { RTMI_GATHER_NONE = 0,        /* one replica: nothing to move */
+       RTMI_GATHER_SAME_DEVICE = 1, /* replicas share replica 0's device (rehearsal on a one-GPU host): device-to-device copies */
+       RTMI_GATHER_PEER_COPY = 2,   /* distinct devices, hipMemcpyPeerAsync (RTMI_MULTI_GATHER=copy, or RCCL unusable on this host) */
+       RTMI_GATHER_RCCL = 3 };      /* ONE grouped ncclGather on the library's communicator set */
+int rtmi_last_gather_path(rtmi_ctx *ctx0, int32_t *path);
+/* Can the RCCL library `soname` be opened and does it export the entry points the in-library gather binds (ncclCommInitAll,
+ * ncclCommDestroy, ncclGroupStart, ncclGroupEnd, ncclGather, ncclGetErrorString)?  soname = NULL: the names the gather itself tries
+ * ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", or $RTMI_RCCL_LIB).  Touches no device.  RTMI_E_DEVICE + the loader's
+ * message when not. */
+int rtmi_rccl_probe(const char *soname);
+/* *idle = 1 when nothing is pending on the context's own stream (hipStreamQuery). */
+int rtmi_stream_idle(rtmi_ctx *ctx, int32_t *idle);
+/* Sample passes (trace-kernel launches) the context's most recent render took: the per-sample colour buffer is sized by option
+ * "workspace_bytes", by the HBM that is free when it has to grow (at most 80 % of it) and, if the allocation still fails, by halving. */
+int rtmi_last_passes(rtmi_ctx *ctx, int32_t *passes);
 /* Milliseconds between the end of replica 0's own render and the end of the gather of the last rtmi_render_multi* on
  * replica 0's context (HIP events on its stream): the transfer plus the wait for the slowest replica. */
 int rtmi_last_gather_ms(rtmi_ctx *ctx0, double *ms);

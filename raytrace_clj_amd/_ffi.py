@@ -25,11 +25,13 @@ SYMBOLS = [
     "rtmi_probe_paths", "rtmi_probe_camera", "rtmi_probe_texture", "rtmi_probe_scatter", "rtmi_probe_rng",
     "rtmi_sample_key", "rtmi_probe_arith", "rtmi_probe_math", "rtmi_last_traversal_counters",
     "rtmi_scene_clone", "rtmi_render_multi", "rtmi_render_multi_device", "rtmi_last_gather_ms",
+    "rtmi_last_gather_path", "rtmi_rccl_probe", "rtmi_stream_idle", "rtmi_last_passes",
 ]
 
 F64, F32 = 0, 1
 ACCEL_FLAT, ACCEL_BVH = 0, 1
 FLAG_TIMING = 1
+GATHER_PATHS = {0: "none", 1: "same-device", 2: "peer-copy", 3: "rccl"}
 SEG_REC = 12
 TILE = 8
 
@@ -89,6 +91,10 @@ def lib():
     L.rtmi_render_multi.argtypes = [i32, C.POINTER(vp), i32, i32, i32, i32, u64, i32, vp, vp, vp]
     L.rtmi_render_multi_device.argtypes = [i32, C.POINTER(vp), i32, i32, i32, i32, u64, i32, vp, vp, vp]
     L.rtmi_last_gather_ms.argtypes = [vp, C.POINTER(dbl)]
+    L.rtmi_last_gather_path.argtypes = [vp, C.POINTER(i32)]
+    L.rtmi_rccl_probe.argtypes = [C.c_char_p]
+    L.rtmi_stream_idle.argtypes = [vp, C.POINTER(i32)]
+    L.rtmi_last_passes.argtypes = [vp, C.POINTER(i32)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("rtmi_version",):

@@ -43,20 +43,19 @@ constexpr int kBlock = 256;
 #define RTMI_TRACE_BLOCK 256
 #endif
 constexpr int kTraceBlock = RTMI_TRACE_BLOCK; // threads per workgroup of the trace kernel
-// Diagnostic build only (make stamps -> librtmi_stamps.so): s_memtime around the phases of a loop trip, summed per wave and
-// added to g_stamps[phase], printed to stderr after every render.  Never defined in the shipped library.
+// Diagnostic build only (make stamps -> librtmi_stamps.so): per-phase wave ticks and lane-ticks (ph_stamp, rtmi_device.h), summed over the
+// launch's waves into g_phase and printed to stderr after every render, with the workgroups' start / end times.  Never defined in the
+// shipped library.
 #ifdef RTMI_STAMPS
-#define RTMI_STAMP_DECL unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = stamp_now(); const unsigned long long st_wg0 = real_now(); \
-    if (lane == 0) for (int k_ = 0; k_ < 18; ++k_) g_st_sub[threadIdx.x >> 6][k_] = 0;
-#define RTMI_STAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = stamp_now(); st_acc[k] += n_ - st_t; st_t = n_; __builtin_amdgcn_sched_barrier(0); }
 __device__ unsigned long long g_wg_t[2][4096]; // s_memrealtime (100 MHz) at workgroup start / end
 __device__ inline unsigned long long real_now() { unsigned long long t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }
-#define RTMI_STAMP_FLUSH(cnt) if (lane == 0) { for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_stamps[k_], st_acc[k_]); \
-                                               for (int k_ = 8; k_ < 16; ++k_) atomicAdd(&g_stamps[k_], g_st_sub[threadIdx.x >> 6][k_]); } \
+#define RTMI_STAMP_DECL const unsigned long long st_wg0 = real_now(); \
+    if (lane == 0) for (int k_ = 0; k_ < 50; ++k_) g_ph[threadIdx.x >> 6][k_] = 0; \
+    ph_stamp(-1); for (int k_ = 0; k_ < 32; ++k_) ph_stamp(PH_CAL);
+#define RTMI_STAMP_FLUSH(cnt) if (lane == 0) for (int k_ = 0; k_ < 48; ++k_) if (g_ph[threadIdx.x >> 6][k_]) atomicAdd(&g_phase[k_], g_ph[threadIdx.x >> 6][k_]); \
     __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4096) { g_wg_t[0][blockIdx.x] = st_wg0; g_wg_t[1][blockIdx.x] = real_now(); }
 #else
 #define RTMI_STAMP_DECL
-#define RTMI_STAMP(k)
 #define RTMI_STAMP_FLUSH(cnt)
 #endif
 #ifndef RTMI_MIN_WAVES
@@ -203,13 +202,10 @@ __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per
 
 // core.clj:43-51: jittered (u, v) for sample s of pixel (i, j), then the camera ray.
 template <typename R> __device__ inline void start_sample(SceneRef sc, const TraceParams &tp, int i, int j, int s, Path<R> &P) {
-    RTMI_SUBSTAMP(-1)
     seed_stream(P, sample_key(tp.seed, (u64)j * (u64)tp.nx + (u64)i, (u64)s), 0u);
     const R u = ((R)(float)i + next_uniform(P)) / (R)tp.nx;
     const R v = ((R)(float)j + next_uniform(P)) / (R)tp.ny;
-    RTMI_SUBSTAMP(13)
     get_ray<R>(sc, u, v, P);
-    RTMI_SUBSTAMP(14)
     P.ar = P.ag = P.ab = R(1);
     P.depth = tp.depth;
 }
@@ -251,7 +247,7 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
 
     RTMI_STAMP_DECL
     for (;;) {
-        RTMI_STAMP(5) // loop overhead / tail
+        RTMI_PH(PH_LOOP) // loop overhead / tail
         // ---- refill dead lanes ------------------------------------------------------------------------------------------
         if (STASH) {
         // Camera rays are generated 64 at a time by the WHOLE wave (key, jitter, lens disk loop, get-ray: start_sample at full
@@ -286,6 +282,7 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
                     start_sample<R>(sc, tp, x, tp.ny - 1 - y, s, Q); // j = ny-1-y (core.clj:105)
                     st_ox = Q.ox; st_oy = Q.oy; st_oz = Q.oz; st_dx = Q.dx; st_dy = Q.dy; st_dz = Q.dz; st_time = Q.time; st_rs = Q.rs;
                     st_item = m;
+                    RTMI_PH(PH_REFILL_GEN)
                 }
                 s_head = 0u;
             }
@@ -293,7 +290,9 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
             const unsigned rank = (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
             const bool take = !alive && rank < avail;
             const int src = take ? (int)(s_head + rank) : lane;
-            const R f_ox = __shfl(st_ox, src), f_oy = __shfl(st_oy, src), f_oz = __shfl(st_oz, src);
+            R f_ox, f_oy, f_oz;
+            if (sc.cam_fixed_origin) { f_ox = (R)sc.cam[0]; f_oy = (R)sc.cam[1]; f_oz = (R)sc.cam[2]; } // wave-uniform: 6 cross-lane moves fewer per deal
+            else { f_ox = __shfl(st_ox, src); f_oy = __shfl(st_oy, src); f_oz = __shfl(st_oz, src); }
             const R f_dx = __shfl(st_dx, src), f_dy = __shfl(st_dy, src), f_dz = __shfl(st_dz, src), f_time = __shfl(st_time, src);
             const u64 f_rs = __shfl(st_rs, src);
             const unsigned f_item = __shfl(st_item, src);
@@ -339,7 +338,7 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
         }
         if (MULTI) { if (!__syncthreads_or(alive ? 1 : 0)) break; }
         else { if (!__any(alive ? 1 : 0)) break; }
-        RTMI_STAMP(0) // refill
+        RTMI_PH(PH_REFILL_DEAL) // refill: claims, dealing stash entries to dead lanes
 
         // ---- one iteration of `color` for every live lane ---------------------------------------------
         // SLICED (BVH kernels): the traversal hands the wave back as soon as fewer than tp.suspend_lanes lanes are still in the tree
@@ -349,7 +348,7 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
         R best_t; int best_i;
         intersect_world<R, MULTI, VARIANT, EXT, COUNT, SLICED>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i, ntrav,
                                                                &mid, exhausted ? 0 : tp.suspend_lanes);
-        RTMI_STAMP(1) // intersection
+        RTMI_PH(PH_BVH_POST) // intersection: what the phases inside did not book (suspend bookkeeping, call overhead)
         if (!SLICED || __any(alive && !mid)) { // a trip in which no lane finished its segment has nothing to shade
         if (alive) {
             if (!mid) ++nrays;
@@ -359,10 +358,11 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
                 R *out = reinterpret_cast<R *>(tp.samples) + (size_t)out_item * 3;
                 out[0] = emit[0]; out[1] = emit[1]; out[2] = emit[2];
                 alive = false;
+                RTMI_PH(PH_STORE)
             }
         }
         }
-        RTMI_STAMP(2) // shading
+        RTMI_PH(PH_STORE) // shading: what its phases did not book
     }
     RTMI_STAMP_FLUSH(tp.counters)
     // total-rays: wave reduction, one atomic per wave
@@ -658,6 +658,15 @@ struct rtmi_ctx {
     DevBuf multi; // rtmi_render_multi*: this replica's record (tiles + counters); on replica 0 the gathered records of all replicas
     hipEvent_t ev_done = nullptr, ev_g0 = nullptr, ev_g1 = nullptr; // multi-device: render finished / gather interval on replica 0
     bool have_gather = false;
+    int last_gather_path = RTMI_GATHER_NONE; // how the last rtmi_render_multi* on this context (as replica 0) gathered
+    // copy-branch gather: replica 0's stream copies OUT of this replica's record; the event (created on replica 0's device, recorded on
+    // its stream after the copy) is what this replica's stream waits for before it renders into the record again
+    hipEvent_t ev_consumed = nullptr;
+    int ev_consumed_device = -1;
+    bool consume_pending = false;
+    int fail_next_render = 0;  // option "test_fail_next_render" (test hook): the next render on this context fails before it launches anything
+    int fail_allocs = 0;       // option "test_fail_allocs" (test hook): the next n sample-buffer allocations fail as if HBM were exhausted
+    int last_passes = 0;       // sample passes of the most recent render (rtmi_last_passes)
     int last_grid = 0; // workgroups of the last trace launch (diagnostics)
     std::vector<int> tile_ids_host;
     int tile_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
@@ -774,6 +783,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
     int rc = ensure_tile_ids(c, nx, ny, first, stride, rg, st, &n_local);
     if (rc) return rc;
     c->last_stream = st;
+    if (c->fail_next_render) { c->fail_next_render = 0; return fail(RTMI_E_DEVICE, "render failed (injected by the test hook test_fail_next_render)"); }
     rc = c->counters.ensure(8 * sizeof(u64)); // [0..1] the metrics when the caller passes no buffer, [2] the work-queue head, [3..4] traversal counters
     if (rc) return rc;
     if (d_counters) HIP_TRY(hipMemsetAsync(d_counters, 0, 2 * sizeof(u64), st));
@@ -788,8 +798,27 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
     // the work queue is indexed with 32 bits: items per pass (+ one claim per wave past the end) must stay below 2^32
     while (s_per_pass > 1 && (long long)n_local * s_per_pass * 64 >= 0xf0000000ll) s_per_pass /= 2;
     if ((long long)n_local * s_per_pass * 64 >= 0xf0000000ll) return fail(RTMI_E_ARG, "frame too large for one pass: %d tiles per rank", n_local);
-    rc = c->samples.ensure(per_sample * (size_t)s_per_pass);
-    if (rc) return rc;
+    if (per_sample * (size_t)s_per_pass > c->samples.bytes) {
+        // The buffer has to grow.  The budget is what the option allows AND what the device can give: at most kFreeShare of the HBM that
+        // is free right now (plus what this context's buffer already holds) -- a host that shares the GPU (PyTorch's caching allocator, a
+        // second render slot) gets more passes instead of RTMI_E_NOMEM.  If the allocation still fails, halve the pass and retry.
+        constexpr double kFreeShare = 0.8;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double avail = kFreeShare * (double)free_b + (double)c->samples.bytes;
+            const int fit = (int)std::max<double>(1.0, std::min<double>((double)s_per_pass, avail / (double)per_sample));
+            s_per_pass = std::min(s_per_pass, fit);
+        }
+        for (;;) {
+            if (c->fail_allocs > 0) { c->fail_allocs--; c->samples.release(); rc = fail(RTMI_E_NOMEM, "hipMalloc(%zu bytes) failed (injected by the test hook)", per_sample * (size_t)s_per_pass); }
+            else rc = c->samples.ensure(per_sample * (size_t)s_per_pass);
+            if (!rc) break;
+            (void)hipGetLastError(); // a failed hipMalloc leaves its error sticky
+            if (s_per_pass == 1) return rc;
+            s_per_pass = (s_per_pass + 1) / 2;
+        }
+    }
+    c->last_passes = (ns + s_per_pass - 1) / s_per_pass;
     if (s_per_pass < ns) {
         rc = c->accum.ensure((size_t)n_local * 64 * 3 * sizeof(R));
         if (rc) return rc;
@@ -876,14 +905,9 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
     {
         const int grid_trace_dbg = c->last_grid;
         HIP_TRY(hipStreamSynchronize(st));
-        unsigned long long h[16] = {0}, z[16] = {0};
-        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)));
-        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)));
-        unsigned long long h2[8] = {0};
-        HIP_TRY(hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_stamps2), sizeof(h2)));
-        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps2), z, sizeof(h2)));
-        fprintf(stderr, "[stamps] bvh: inner ticks %.3g leaf ticks %.3g | inner trips %llu (lanes/trip %.1f) leaf trips %llu (lanes/trip %.1f) calls %llu\n",
-                (double)h2[0], (double)h2[1], h2[2], (double)h2[3] / (double)(h2[2] ? h2[2] : 1), h2[4], (double)h2[5] / (double)(h2[4] ? h2[4] : 1), h2[6]);
+        unsigned long long h[48] = {0}, z[48] = {0};
+        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)));
         {
             static unsigned long long wt[2][4096];
             HIP_TRY(hipMemcpyFromSymbol(wt, HIP_SYMBOL(g_wg_t), sizeof(wt)));
@@ -894,12 +918,27 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             fprintf(stderr, "[stamps] workgroup start (ms after first): median %.3f max %.3f | end: min %.3f p10 %.3f median %.3f p90 %.3f max %.3f (last pass, %d workgroups)\n",
                     b[g / 2], b[g - 1], e[0], e[g / 10], e[g / 2], e[g * 9 / 10], e[g - 1], g);
         }
-        double tot = 0; for (int k = 0; k < 6; ++k) tot += (double)h[k];
-        fprintf(stderr, "[stamps] refill %.1f%% intersect %.1f%% shade %.1f%% loop %.1f%%  total %.3g wave-ticks\n", 100 * h[0] / tot,
-                100 * h[1] / tot, 100 * h[2] / tot, 100 * h[5] / tot, tot);
-        fprintf(stderr, "[stamps] of the total: resolve_hit %.1f%% | scatter: |d| %.1f%% rand-in-unit-sphere %.1f%% directions %.1f%% texture %.1f%% | "
-                        "start_sample: key+uv %.1f%% get-ray %.1f%%\n", 100 * h[8] / tot, 100 * h[9] / tot, 100 * h[10] / tot, 100 * h[11] / tot,
-                100 * h[12] / tot, 100 * h[13] / tot, 100 * h[14] / tot);
+        static const char *names[PH_N] = {"loop/tail", "refill: generate 64 camera rays", "refill: claim + deal", "bvh: ray setup / resume", "bvh: big primitives (exact)",
+                                          "bvh: descent (node visits)", "bvh: leaf exact tests", "bvh: loop control / park", "shade: hit record", "shade: |d| normalise",
+                                          "shade: rand-in-unit-sphere", "shade: material record + directions", "shade: texture", "shade: store / rest", "shade: sphere uv", "(stamp calibration)"};
+        // every interval begins with the bookkeeping of the stamp that opened it: subtract the cost of one stamp (PH_CAL: back-to-back stamps) per stamp
+        const double per_stamp = h[32 + PH_CAL] ? (double)h[PH_CAL] / (double)h[32 + PH_CAL] : 0.0;
+        double tk[PH_N], lk[PH_N], tot = 0, totl = 0, raw = 0;
+        for (int k = 0; k < PH_N; ++k) {
+            raw += (double)h[k];
+            const double t = (double)h[k], c = std::min(t, per_stamp * (double)h[32 + k]);
+            tk[k] = k == PH_CAL ? 0.0 : t - c;
+            lk[k] = t > 0 ? (double)h[16 + k] * (tk[k] / t) : 0.0;
+            tot += tk[k]; totl += lk[k];
+        }
+        fprintf(stderr, "[phases] one stamp = %.0f ticks; stamps took %.1f %% of the %.4g wave-ticks of this (diagnostic) launch and are subtracted below\n", per_stamp, 100 * (raw - tot) / raw, raw);
+        fprintf(stderr, "[phases] %-36s %8s %8s %10s %10s %12s\n", "phase", "ticks %", "lanes", "masked %", "useful %", "stamps");
+        for (int k = 0; k < PH_N; ++k) {
+            if (!h[k] || k == PH_CAL) continue;
+            const double t = tk[k], l = lk[k];
+            fprintf(stderr, "[phases] %-36s %8.2f %8.1f %10.2f %10.2f %12llu\n", names[k], 100 * t / tot, t > 0 ? l / t : 0.0, 100 * (64 * t - l) / (64 * tot), 100 * l / (64 * tot), h[32 + k]);
+        }
+        fprintf(stderr, "[phases] %-36s %8.2f %8.1f %10.2f %10.2f   (%.4g wave-ticks)\n", "total", 100.0, totl / tot, 100 * (64 * tot - totl) / (64 * tot), 100 * totl / (64 * tot), tot);
     }
 #endif
     return RTMI_OK;
@@ -1234,6 +1273,7 @@ RTMI_EXPORT int rtmi_shutdown(rtmi_ctx *c) {
 #endif
     c->samples.release(); c->accum.release(); c->tiles.release(); c->tile_ids.release(); c->counters.release(); c->scratch_lin.release(); c->multi.release();
     for (hipEvent_t e : {c->ev_done, c->ev_g0, c->ev_g1}) if (e) (void)hipEventDestroy(e);
+    if (c->ev_consumed) { (void)hipSetDevice(c->ev_consumed_device); (void)hipEventDestroy(c->ev_consumed); (void)hipSetDevice(c->device); }
     for (auto &e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (hipEvent_t e : c->events_r) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -1251,6 +1291,8 @@ RTMI_EXPORT int rtmi_set_option(rtmi_ctx *c, const char *name, int64_t value) {
     if (!std::strcmp(name, "timing")) { if (value) c->flags |= RTMI_FLAG_TIMING; else c->flags &= ~RTMI_FLAG_TIMING; return RTMI_OK; }
     if (!std::strcmp(name, "scan_variant")) { if (value < 0 || value > 3) return fail(RTMI_E_ARG, "scan_variant must be 0..3"); c->scan_variant = (int)value; return RTMI_OK; }
     if (!std::strcmp(name, "count_traversal")) { c->count_traversal = value ? 1 : 0; return RTMI_OK; }
+    if (!std::strcmp(name, "test_fail_next_render")) { c->fail_next_render = value ? 1 : 0; return RTMI_OK; }
+    if (!std::strcmp(name, "test_fail_allocs")) { c->fail_allocs = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64)); return RTMI_OK; }
     if (!std::strcmp(name, "suspend_lanes")) { if (value < 0 || value > 64) return fail(RTMI_E_ARG, "suspend_lanes must be 0..64"); c->suspend_lanes = (int)value; return RTMI_OK; }
     if (!std::strcmp(name, "accel")) {
         if (value == RTMI_ACCEL_FLAT || value == RTMI_ACCEL_BVH) { c->accel = (int)value; return RTMI_OK; }
@@ -1374,6 +1416,13 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     DevScene &d = s->dev;
     d.n_static = (int)stat_orig.size(); d.n_moving = (int)mov_orig.size(); d.n_tex = n_tex; d.cam_kind = cam_kind;
     std::memcpy(d.cam, cam, 24 * sizeof(double));
+    { // get-ray's origin is cam origin + lens offset; with aperture 0 the offset is (+-0, +-0, +-0) (camera.clj:39-44: lens-radius * rand-in-unit-disk), and
+      // x + (+-0) = x bit for bit for every x except -0 (whose sum with +0 is +0): then, and for the pinhole camera, all rays share one origin
+        bool fixed = cam_kind == RTMI_CAM_PINHOLE || cam[21] == 0.0;
+        for (int k = 0; k < 3; ++k) fixed = fixed && !(cam[k] == 0.0 && std::signbit(cam[k])) && std::isfinite(cam[k]);
+        for (int k = 12; k < 18; ++k) fixed = fixed && std::isfinite(cam[k]);
+        d.cam_fixed_origin = fixed ? 1 : 0;
+    }
     std::vector<int> mk(mat_kind, mat_kind + n_mats), mt(mat_tex, mat_tex + n_mats), tk(tex_kind, tex_kind + n_tex), tc(tex_child, tex_child + 2 * (size_t)n_tex);
     std::vector<double> mp(mat_param, mat_param + n_mats), tpv(tex_param, tex_param + (size_t)n_tex * RTMI_TEX_STRIDE);
     int rc = RTMI_OK;
@@ -1538,7 +1587,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
         std::vector<int> km((size_t)std::max(n_prims, 1) * 2, 0);
         for (int i = 0; i < n_prims; ++i) { km[2 * (size_t)i] = pk_dev[(size_t)i]; km[2 * (size_t)i + 1] = pm[(size_t)i]; }
         if (!rc) rc = upload(s, km, &d.prim_km);
-        std::vector<double> mrec((size_t)std::max(n_mats, 1) * 12, 0.0);
+        std::vector<double> mrec((size_t)std::max(n_mats, 1) * 12, 0.0), mgrad((size_t)std::max(n_mats, 1) * 12, 0.0);
         for (int m = 0; m < n_mats; ++m) {
             MatRec r;
             std::memset(&r, 0, sizeof(r));
@@ -1552,6 +1601,10 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
             }
             r.tex_kind = (r.tex >= 0 && r.tex < n_tex) ? tex_kind[r.tex] : -1;
             if (r.tex_kind == RTMI_TEX_CONSTANT) { const double *tp = tex_param + (size_t)r.tex * RTMI_TEX_STRIDE; r.r = tp[0]; r.g = tp[1]; r.b = tp[2]; }
+            if (r.tex_kind == RTMI_TEX_UVGRADIENT) { // texture.clj:26-34: co cu cv cuv travel with the material
+                std::memcpy(&mgrad[(size_t)m * 12], tex_param + (size_t)r.tex * RTMI_TEX_STRIDE, 12 * sizeof(double));
+                r.tex_kind = RTMI_TEX_GRADIENT_REC;
+            }
             if (r.tex_kind == RTMI_TEX_CHECKER) { // both children Constant: the whole texture fits the record
                 const int c0 = tex_child[2 * (size_t)r.tex], c1 = tex_child[2 * (size_t)r.tex + 1];
                 if (c0 >= 0 && c0 < n_tex && c1 >= 0 && c1 < n_tex && tex_kind[c0] == RTMI_TEX_CONSTANT && tex_kind[c1] == RTMI_TEX_CONSTANT) {
@@ -1565,6 +1618,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
             std::memcpy(&mrec[(size_t)m * 12], &r, sizeof(r));
         }
         if (!rc) rc = upload(s, mrec, &d.mat_rec);
+        if (!rc) rc = upload(s, mgrad, &d.mat_grad);
     }
     if (!rc) rc = upload(s, pm, &d.prim_mat);
     if (!rc) rc = upload(s, mk, &d.mat_kind);
@@ -1795,20 +1849,22 @@ struct Rccl {
 };
 std::mutex g_multi_mu;
 Rccl g_rccl;
-bool g_rccl_failed = false; // RCCL could not be opened / initialised once: later gathers use peer copies
+bool g_rccl_failed = false; // RCCL could not be opened / initialised / a gather failed once: later gathers use copies
 std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms; // one communicator set per device list (ncclCommInitAll), kept for the process
 
-bool rccl_load() {
-    Rccl &R = g_rccl;
-    if (R.tried) return R.h != nullptr;
-    R.tried = true;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        R.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+// Opens the first of `names` that dlopen accepts and binds the six entry points the gather needs.  On failure R.h stays null and
+// R.err says why (dlerror() is read ONCE per failure: a second call returns NULL).
+bool rccl_open(Rccl &R, const std::vector<std::string> &names) {
+    std::string first_err;
+    for (const std::string &name : names) {
+        R.h = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
         if (R.h) break;
+        const char *e = dlerror();
+        if (first_err.empty()) first_err = std::string("dlopen(") + name + "): " + (e ? e : "not found");
     }
-    if (!R.h) { R.err = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); return false; }
+    if (!R.h) { R.err = first_err.empty() ? std::string("no library name given") : first_err; return false; }
     bool ok = true;
-    auto sym = [&](const char *n) { void *p = dlsym(R.h, n); if (!p) { ok = false; R.err = std::string("librccl lacks ") + n; } return p; };
+    auto sym = [&](const char *n) { void *p = dlsym(R.h, n); if (!p && ok) { ok = false; R.err = std::string("the RCCL library lacks ") + n; } return p; };
     R.CommInitAll = reinterpret_cast<decltype(R.CommInitAll)>(sym("ncclCommInitAll"));
     R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
     R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(sym("ncclGroupStart"));
@@ -1819,17 +1875,43 @@ bool rccl_load() {
     return ok;
 }
 
-#define NCCL_TRY(expr)                                                                                   \
-    do {                                                                                                 \
-        ncclResult_t r_ = (expr);                                                                        \
-        if (r_ != ncclSuccess) return fail(RTMI_E_DEVICE, "%s: %s", #expr, g_rccl.GetErrorString(r_));   \
-    } while (0)
+std::vector<std::string> rccl_names() {
+    if (const char *e = std::getenv("RTMI_RCCL_LIB")) return {std::string(e)}; // another build of RCCL, or a bogus name to rehearse the fallback
+    return {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+}
+
+bool rccl_load() {
+    Rccl &R = g_rccl;
+    if (R.tried) return R.h != nullptr;
+    R.tried = true;
+    return rccl_open(R, rccl_names());
+}
 
 int ensure_event(hipEvent_t *e) {
     if (!*e) HIP_TRY(hipEventCreate(e));
     return RTMI_OK;
 }
+
+// a communicator set that produced an error is not used again: destroy it and let later gathers copy
+void rccl_give_up(const std::vector<int> &devs) {
+    auto it = g_comms.find(devs);
+    if (it != g_comms.end()) {
+        for (ncclComm_t cm : it->second) if (cm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(cm);
+        g_comms.erase(it);
+    }
+    g_rccl_failed = true;
+}
 } // namespace
+
+// Can the RCCL library `soname` (NULL: the names the gather itself tries, or $RTMI_RCCL_LIB) be opened, and does it export the entry
+// points the in-library gather binds?  No device is touched.
+RTMI_EXPORT int rtmi_rccl_probe(const char *soname) {
+    Rccl R;
+    const bool ok = rccl_open(R, soname ? std::vector<std::string>{std::string(soname)} : rccl_names());
+    if (!ok) return fail(RTMI_E_DEVICE, "%s", R.err.c_str());
+    dlclose(R.h);
+    return RTMI_OK;
+}
 
 RTMI_EXPORT int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, int32_t nx, int32_t ny, int32_t ns, int32_t depth, uint64_t seed,
                                          int32_t precision, void *d_out_linear, void *d_out_rgb8, void *d_out_counters) {
@@ -1853,8 +1935,13 @@ RTMI_EXPORT int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, i
         devs[(size_t)r] = scenes[r]->ctx->device;
         for (int q = 0; q < r; ++q) distinct = distinct && devs[(size_t)q] != devs[(size_t)r];
     }
-    const char *force = std::getenv("RTMI_MULTI_GATHER"); // "copy": never RCCL (diagnostics); "rccl": fail instead of falling back
-    bool use_rccl = n > 1 && distinct && !(force && !std::strcmp(force, "copy")) && !g_rccl_failed;
+    // Which gather: RCCL whenever the replicas sit on distinct devices (n > 1); copies when they share a device (RCCL refuses duplicate
+    // devices in one communicator).  RTMI_MULTI_GATHER = "copy": never RCCL; "rccl": RCCL or an error -- no silent substitution -- and also
+    // for n = 1 (a one-rank communicator: the whole path -- dlopen, ncclCommInitAll, grouped in-place ncclGather -- on a one-GPU host).
+    const char *force = std::getenv("RTMI_MULTI_GATHER");
+    const bool want_copy = force && !std::strcmp(force, "copy"), want_rccl = force && !std::strcmp(force, "rccl");
+    if (want_rccl && !distinct) return fail(RTMI_E_ARG, "RTMI_MULTI_GATHER=rccl needs replicas on distinct devices (RCCL refuses one device twice in a communicator)");
+    bool use_rccl = distinct && !want_copy && (want_rccl || (n > 1 && !g_rccl_failed));
     std::vector<ncclComm_t> *comms = nullptr;
     if (use_rccl) { // the library owns its communicators: one set per device list, created on first use, kept for the process
         std::string why;
@@ -1870,12 +1957,23 @@ RTMI_EXPORT int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, i
             if (why.empty()) comms = &it->second;
         }
         if (!why.empty()) { // no usable RCCL: the gather falls back to peer copies (same result, ordered with events), once and for all
-            if (force && !std::strcmp(force, "rccl")) return fail(RTMI_E_DEVICE, "multi-device gather: %s", why.c_str());
+            if (want_rccl) return fail(RTMI_E_DEVICE, "multi-device gather: %s", why.c_str());
             fprintf(stderr, "[rtmi] multi-device gather falls back to hipMemcpyPeerAsync: %s\n", why.c_str());
             g_rccl_failed = true;
             use_rccl = false;
         }
     }
+    // From here on work is enqueued on the replicas' streams.  An error after the first launch must not return with kernels still in
+    // flight on streams the caller believes idle (it may destroy the contexts next): bail() waits for every stream touched so far.
+    int launched = 0;
+    auto bail = [&](int code) {
+        const std::string keep = g_err;
+        for (int r = 0; r < launched; ++r) { (void)hipSetDevice(scenes[r]->ctx->device); (void)hipStreamSynchronize(scenes[r]->ctx->stream); }
+        (void)hipSetDevice(c0->device); (void)hipStreamSynchronize(c0->stream);
+        g_err = keep;
+        return code;
+    };
+#define HIP_BAIL(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(RTMI_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_))); } while (0)
     // 1. every replica renders its tiles (r, r+n, ...) on its own device and stream, straight into its record
     HIP_TRY(hipSetDevice(c0->device));
     int rc = c0->multi.ensure((size_t)n * rec * 8);
@@ -1884,36 +1982,53 @@ RTMI_EXPORT int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, i
     std::vector<char *> recs((size_t)n);
     for (int r = 0; r < n; ++r) {
         rtmi_ctx *cr = scenes[r]->ctx;
-        HIP_TRY(hipSetDevice(cr->device));
+        HIP_BAIL(hipSetDevice(cr->device));
         if (r == 0) recs[0] = gathered; // in place: replica 0's record is the first of the gathered buffer
-        else { rc = cr->multi.ensure(rec * 8); if (rc) return rc; recs[(size_t)r] = reinterpret_cast<char *>(cr->multi.p); }
+        else { rc = cr->multi.ensure(rec * 8); if (rc) return bail(rc); recs[(size_t)r] = reinterpret_cast<char *>(cr->multi.p); }
         char *buf = recs[(size_t)r];
+        if (cr->consume_pending) { // the previous frame's copy out of this record (on another replica 0's stream) must have read it
+            HIP_BAIL(hipStreamWaitEvent(cr->stream, cr->ev_consumed, 0));
+            cr->consume_pending = false;
+        }
+        launched = r + 1;
         if (precision == RTMI_F64) rc = render_tiles_impl<double>(scenes[r], nx, ny, ns, depth, seed, r, n, nullptr, buf, buf + (size_t)per * 192 * 8, cr->stream);
         else rc = render_tiles_impl<float>(scenes[r], nx, ny, ns, depth, seed, r, n, nullptr, buf, buf + (size_t)per * 192 * 8, cr->stream);
-        if (rc) return rc;
-        if (!use_rccl && r > 0) { rc = ensure_event(&cr->ev_done); if (rc) return rc; HIP_TRY(hipEventRecord(cr->ev_done, cr->stream)); }
+        if (rc) return bail(rc);
+        if (!use_rccl && r > 0) { rc = ensure_event(&cr->ev_done); if (rc) return bail(rc); HIP_BAIL(hipEventRecord(cr->ev_done, cr->stream)); }
     }
     // 2. ONE gather to replica 0's device
-    HIP_TRY(hipSetDevice(c0->device));
+    HIP_BAIL(hipSetDevice(c0->device));
     rc = ensure_event(&c0->ev_g0); if (!rc) rc = ensure_event(&c0->ev_g1);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(c0->ev_g0, c0->stream));
+    if (rc) return bail(rc);
+    HIP_BAIL(hipEventRecord(c0->ev_g0, c0->stream));
     if (use_rccl) {
-        NCCL_TRY(g_rccl.GroupStart());
-        for (int r = 0; r < n; ++r) {
-            const ncclResult_t e = g_rccl.Gather(recs[(size_t)r], r == 0 ? gathered : nullptr, rec, ncclUint64, 0, (*comms)[(size_t)r], scenes[r]->ctx->stream);
-            if (e != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(RTMI_E_DEVICE, "ncclGather(rank %d): %s", r, g_rccl.GetErrorString(e)); }
+        ncclResult_t e = g_rccl.GroupStart();
+        for (int r = 0; r < n && e == ncclSuccess; ++r)
+            e = g_rccl.Gather(recs[(size_t)r], r == 0 ? gathered : nullptr, rec, ncclUint64, 0, (*comms)[(size_t)r], scenes[r]->ctx->stream);
+        const ncclResult_t e2 = g_rccl.GroupEnd();
+        if (e == ncclSuccess) e = e2;
+        if (e != ncclSuccess) { // this communicator set is not trusted again: later calls gather by copies
+            const int code = fail(RTMI_E_DEVICE, "ncclGather: %s", g_rccl.GetErrorString(e));
+            rccl_give_up(devs);
+            return bail(code);
         }
-        NCCL_TRY(g_rccl.GroupEnd());
+        c0->last_gather_path = RTMI_GATHER_RCCL;
     } else {
-        for (int r = 1; r < n; ++r) { // replicas sharing a device (rehearsal on a one-GPU host), or RTMI_MULTI_GATHER=copy: plain copies on replica 0's stream
+        bool peer = false;
+        for (int r = 1; r < n; ++r) { // replicas sharing a device (rehearsal on a one-GPU host), RTMI_MULTI_GATHER=copy, or no usable RCCL: copies on replica 0's stream
             rtmi_ctx *cr = scenes[r]->ctx;
-            HIP_TRY(hipStreamWaitEvent(c0->stream, cr->ev_done, 0));
-            if (cr->device == c0->device) HIP_TRY(hipMemcpyAsync(gathered + (size_t)r * rec * 8, recs[(size_t)r], rec * 8, hipMemcpyDeviceToDevice, c0->stream));
-            else HIP_TRY(hipMemcpyPeerAsync(gathered + (size_t)r * rec * 8, c0->device, recs[(size_t)r], cr->device, rec * 8, c0->stream));
+            HIP_BAIL(hipStreamWaitEvent(c0->stream, cr->ev_done, 0));
+            if (cr->device == c0->device) HIP_BAIL(hipMemcpyAsync(gathered + (size_t)r * rec * 8, recs[(size_t)r], rec * 8, hipMemcpyDeviceToDevice, c0->stream));
+            else { peer = true; HIP_BAIL(hipMemcpyPeerAsync(gathered + (size_t)r * rec * 8, c0->device, recs[(size_t)r], cr->device, rec * 8, c0->stream)); }
+            // replica r's NEXT render into its record waits for this copy (its stream is not otherwise ordered with replica 0's)
+            if (cr->ev_consumed && cr->ev_consumed_device != c0->device) { (void)hipSetDevice(cr->ev_consumed_device); (void)hipEventDestroy(cr->ev_consumed); cr->ev_consumed = nullptr; HIP_BAIL(hipSetDevice(c0->device)); }
+            if (!cr->ev_consumed) { HIP_BAIL(hipEventCreateWithFlags(&cr->ev_consumed, hipEventDisableTiming)); cr->ev_consumed_device = c0->device; }
+            HIP_BAIL(hipEventRecord(cr->ev_consumed, c0->stream));
+            cr->consume_pending = true;
         }
+        c0->last_gather_path = n == 1 ? RTMI_GATHER_NONE : (peer ? RTMI_GATHER_PEER_COPY : RTMI_GATHER_SAME_DEVICE);
     }
-    HIP_TRY(hipEventRecord(c0->ev_g1, c0->stream));
+    HIP_BAIL(hipEventRecord(c0->ev_g1, c0->stream));
     c0->have_gather = true;
     // 3. replica 0 un-tiles, quantises and sums the counters
     if (d_out_linear || d_out_rgb8) {
@@ -1921,13 +2036,14 @@ RTMI_EXPORT int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, i
         hipLaunchKernelGGL((assemble_kernel<double>), dim3((unsigned)((npx + kBlock - 1) / kBlock)), dim3(kBlock), 0, c0->stream,
                            reinterpret_cast<const double *>(gathered), n, rec, tiles_x_of(nx), nx, ny,
                            reinterpret_cast<double *>(d_out_linear), reinterpret_cast<unsigned char *>(d_out_rgb8));
-        HIP_TRY(hipGetLastError());
+        HIP_BAIL(hipGetLastError());
     }
     if (d_out_counters) {
         hipLaunchKernelGGL(sum_counters_kernel, dim3(1), dim3(64), 0, c0->stream, reinterpret_cast<const u64 *>(gathered), n, rec, (size_t)per * 192,
                            reinterpret_cast<u64 *>(d_out_counters));
-        HIP_TRY(hipGetLastError());
+        HIP_BAIL(hipGetLastError());
     }
+#undef HIP_BAIL
     return RTMI_OK;
 }
 
@@ -1951,7 +2067,29 @@ RTMI_EXPORT int rtmi_render_multi(int32_t n, rtmi_scene *const *scenes, int32_t 
     if (out_linear) HIP_TRY(hipMemcpy(out_linear, d_lin, npx * 3 * sizeof(double), hipMemcpyDeviceToHost));
     if (out_rgb8) HIP_TRY(hipMemcpy(out_rgb8, d_q, npx * 3, hipMemcpyDeviceToHost));
     if (out_counters) HIP_TRY(hipMemcpy(out_counters, d_cnt, 2 * sizeof(u64), hipMemcpyDeviceToHost));
-    for (int r = 1; r < n; ++r) { HIP_TRY(hipSetDevice(scenes[r]->ctx->device)); HIP_TRY(hipStreamSynchronize(scenes[r]->ctx->stream)); }
+    for (int r = 1; r < n; ++r) { HIP_TRY(hipSetDevice(scenes[r]->ctx->device)); HIP_TRY(hipStreamSynchronize(scenes[r]->ctx->stream)); scenes[r]->ctx->consume_pending = false; }
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_last_gather_path(rtmi_ctx *c, int32_t *path) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (!c->have_gather) return fail(RTMI_E_STATE, "no multi-device render on this context yet");
+    if (path) *path = c->last_gather_path;
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_stream_idle(rtmi_ctx *c, int32_t *idle) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    HIP_TRY(hipSetDevice(c->device));
+    const hipError_t e = hipStreamQuery(c->stream);
+    if (e != hipSuccess && e != hipErrorNotReady) return fail(RTMI_E_DEVICE, "hipStreamQuery: %s", hipGetErrorString(e));
+    if (idle) *idle = e == hipSuccess ? 1 : 0;
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_last_passes(rtmi_ctx *c, int32_t *passes) {
+    if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    if (passes) *passes = c->last_passes;
     return RTMI_OK;
 }
 

@@ -59,6 +59,7 @@ struct DevScene {
     const int *prim_mat;
     const int *prim_km;      // [n][2] = (prim_kind incl. RTMI_PRIM_NEEDS_UV, prim_mat): one 8-byte fetch for the winner
     const double *mat_rec;   // [n_mats][12]: MatRec -- what scatter needs about a material, in one record (no chain of dependent fetches)
+    const double *mat_grad;  // [n_mats][12]: the four corner colours co cu cv cuv of a material whose texture is a UVGradient (tex_kind RTMI_TEX_GRADIENT_REC)
     const int *mat_kind;
     const int *mat_tex;
     const double *mat_param;
@@ -67,6 +68,7 @@ struct DevScene {
     const double *tex_param; // [n_tex][12]
     const int *tex_child;    // [n_tex][2]
     int cam_kind;
+    int cam_fixed_origin;    // every camera ray starts at cam[0..2] bit for bit (pinhole, or thin lens with aperture 0: origin + (+-0)): the refill need not move origins across lanes
     double cam[24];
 };
 // The descriptor lives in HBM and is read through the constant address space: every field access is a scalar load
@@ -88,29 +90,45 @@ __host__ __device__ inline u64 sample_key(u64 seed, u64 pix, u64 s) {
 }
 __host__ __device__ inline u64 draw_bits(u64 key, u64 d) { return mix64(key + RTMI_GOLD * (d + 1)); }
 
-#ifdef RTMI_STAMPS // diagnostic build only (make stamps): sub-phase times of a wave, accumulated in LDS by its first active lane
-__shared__ unsigned long long g_st_sub[4][18]; // [wave][16] = last stamp
-__device__ inline void substamp(int k) {
+#ifdef RTMI_STAMPS // diagnostic build only (make stamps): where a wave's time and its lane-slots go, phase by phase
+// Every stamp closes the interval since the wave's previous stamp and books it on phase k twice: as wave ticks (s_memtime = shader
+// cycles) and as lane-ticks = ticks x the lanes active AT the stamp.  A stamp therefore sits at the END of the code it names, inside
+// the divergent region if that code runs under a lane mask (a region no lane enters executes no stamp: its few scalar cycles fall to
+// the next stamp).  Accumulators live in LDS, one row per wave, updated by the wave's first active lane; flushed once per launch.
+enum { PH_LOOP = 0, PH_REFILL_GEN, PH_REFILL_DEAL, PH_BVH_SETUP, PH_BIG, PH_DESCENT, PH_LEAF, PH_BVH_POST, PH_HITREC, PH_DNORM, PH_SAMPLER, PH_DIRS, PH_TEXTURE, PH_STORE, PH_UV, PH_CAL, PH_N }; // PH_CAL: back-to-back stamps = the cost of a stamp, subtracted per stamp on the host
+__shared__ unsigned long long g_ph[4][3 * 16 + 2]; // [wave]: ticks[16], lane-ticks[16], stamps[16], last stamp, unused
+__device__ inline void ph_stamp(int k, unsigned lane_trips = 0, unsigned trips = 0) { // trips > 0: book lane_trips / trips lanes per tick instead of the stamp's own mask (loops that count their lanes per trip)
+    __builtin_amdgcn_sched_barrier(0);
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    const unsigned long long ex = __ballot(1);
     const int w = threadIdx.x >> 6;
-    if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) {
-        if (k >= 0) g_st_sub[w][k] += t - g_st_sub[w][16];
-        g_st_sub[w][16] = t;
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
+        const unsigned long long dt = t - g_ph[w][48];
+        if (k >= 0) {
+            g_ph[w][32 + k] += 1;
+            g_ph[w][k] += dt;
+            g_ph[w][16 + k] += trips ? dt * (unsigned long long)lane_trips / (unsigned long long)trips : dt * (unsigned long long)__popcll(ex);
+        }
+        g_ph[w][48] = t;
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
-#define RTMI_SUBSTAMP(k) substamp(k);
+#define RTMI_PH(k) ph_stamp(k);
+#define RTMI_PH_LANES(k, lt, tr) ph_stamp(k, lt, tr);
 #else
-#define RTMI_SUBSTAMP(k)
+#define RTMI_PH(k)
+#define RTMI_PH_LANES(k, lt, tr)
 #endif
 // FP64 square root.  The device libm's correctly rounded sqrt is v_rsq_f64 + nine fma/mul (Goldschmidt, two residual corrections)
 // wrapped in 14 more instructions: a 2^256 pre-scale for arguments below 2^-767 (whose residuals would underflow), the matching
 // post-scale and a v_cmp_class fix-up for 0 / inf.  When every active lane's argument is a finite number >= 2^-767 -- every
-// wave of a render; one integer compare on the high word and a wave-uniform branch decide -- the wrapper does nothing, and the
-// core sequence alone returns the same bits.  Any other wave takes the libm path.
+// lane of a render; one integer compare on the high word decides -- the wrapper does nothing, and the core sequence alone returns
+// the same bits.  The choice is PER LANE (a lane's result is a function of its own argument only, whatever its wave-mates hold):
+// the libm call sits in a branch the wave skips unless one of its lanes needs it.
 __device__ inline double rt_sqrt(double x) {
     const unsigned hi = (unsigned)__double2hiint(x);
-    if (__builtin_expect(__ballot(hi - 0x10000000u >= 0x7ff00000u - 0x10000000u) != 0, 0)) return ::sqrt(x); // hi word of 2^-767 = 0x10000000
+    if (__builtin_expect(hi - 0x10000000u >= 0x7ff00000u - 0x10000000u, 0)) return ::sqrt(x); // hi word of 2^-767 = 0x10000000
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = y * 0.5;
     const double r = ::fma(-h, g, 0.5);
@@ -203,8 +221,12 @@ __device__ inline double div_const(double x, double c, double rc) {
 // and a root costs the last three operations, bit for bit the same quotient whenever the division would not have scaled, i.e.
 // for 2^-969 <= |n| < 2^568 when 2^-200 <= a <= 2^200.  Outside that range the quotients may differ, but then |t| < 2^-768 or
 // |t| >= 2^368 (or t is NaN where the division gives +-inf or 0): with 2^-300 <= t-min and best-so-far <= 2^200 either value fails
-// the same tests (t > t-min, t < best: hitable.clj:195,203), so nothing the scan keeps can differ.  `fast` is wave-uniform: one
-// lane with a outside [2^-200, 2^200] (or a t-min / t-max outside those bounds) sends the wave's ray segment to the plain division.
+// the same tests (t > t-min, t < best: hitable.clj:195,203), so nothing the scan keeps can differ.  `fast` is decided PER LANE from
+// the lane's own a (and the t-min / t-max of the call): a ray's roots never depend on which rays share its wave, so a render is
+// reproducible run to run whatever the work queue deals to a wave.  (Correct rounding of the fast form: r is the reciprocal after two
+// Newton steps, |r - 1/a| <= 2^-104.9 r -- the same r the IEEE sequence holds at that point -- so q = RN(n r) is within 1 ulp of n/a,
+// e = n - a q is exact in one fma, and RN(q + e r) is the correctly rounded quotient by Markstein's theorem; it is the IEEE
+// sequence's own last three operations, probed against the quotient on hard-to-round operands by test_per_ray_reciprocal_division.)
 template <typename R> struct Quot {
     R a;
     __device__ inline R operator()(R n) const { return n / a; }
@@ -223,7 +245,7 @@ template <> __device__ inline Quot<double> make_quot<double>(double a, double tm
     Quot<double> q;
     q.a = a;
     const unsigned hi = (unsigned)__double2hiint(a);
-    q.fast = (__ballot(hi - (823u << 20) >= (400u << 20)) == 0) && tmin >= 0x1p-300 && tmax <= 0x1p200; // biased exponent in [823, 1223)
+    q.fast = (hi - (823u << 20) < (400u << 20)) && tmin >= 0x1p-300 && tmax <= 0x1p200; // biased exponent in [823, 1223)
     double r = __builtin_amdgcn_rcp(a);
     r = ::fma(r, ::fma(-a, r, 1.0), r);
     q.r = ::fma(r, ::fma(-a, r, 1.0), r);
@@ -241,10 +263,27 @@ template <typename R> struct Real;
 template <> struct Real<double> {
     // k = z >> 11 (53 bits) as a double: hi * 2^32 + lo in one fma (exact: k needs 53 bits), then k * 2^-53 (exact)
     __device__ static inline double k53(u64 z) { const u64 k = z >> 11; return ::fma((double)(unsigned)(k >> 32), 4294967296.0, (double)(unsigned)k); }
+#ifndef RTMI_RNG_BITS
+#define RTMI_RNG_BITS 1
+#endif
+#if RTMI_RNG_BITS
+    // The same two values without an integer -> double conversion (two v_cvt_f64_u32 + add + fma per draw): with k = z >> 11 = b 2^52 + f
+    // (b = its top bit, f = its low 52 bits) the double whose bits are (exponent of 2^e | f) is 2^e (1 + f 2^-52) exactly, and
+    //   uniform   = k 2^-53     = (1/2 + f 2^-53) - (b ? 0 : 1/2)      symmetric = k 2^-52 - 1 = (1 + f 2^-52) - (b ? 1 : 2)
+    // are single subtractions of doubles on the same 2^-53 (2^-52) grid with a result below 1 in magnitude: exact, like the forms below.
+    __device__ static inline double from_bits(u64 z, unsigned expo, unsigned sub_b1, unsigned sub_b0) {
+        const unsigned hi = (unsigned)(z >> 32), lo = (unsigned)z;
+        const double m = __hiloint2double((int)(expo | ((hi >> 11) & 0x000fffffu)), (int)__builtin_amdgcn_alignbit(hi, lo, 11));
+        return m - __hiloint2double((int)hi < 0 ? (int)sub_b1 : (int)sub_b0, 0);
+    }
+    __device__ static inline double uniform(u64 z) { return from_bits(z, 0x3fe00000u, 0u, 0x3fe00000u); }
+    __device__ static inline double symmetric(u64 z) { return from_bits(z, 0x3ff00000u, 0x3ff00000u, 0x40000000u); }
+#else
     __device__ static inline double uniform(u64 z) { return k53(z) * (1.0 / 9007199254740992.0); }
     // 2 * uniform - 1 (util.clj:35-36, 46-48) in one fma: k * 2^-52 - 1 = (k - 2^52) * 2^-52 is a 53-bit integer times a power of two,
     // i.e. exact, like the two exact operations (* 2.0 u) and (- ... 1.0) it replaces
     __device__ static inline double symmetric(u64 z) { return ::fma(k53(z), 1.0 / 4503599627370496.0, -1.0); }
+#endif
     __device__ static inline double tmax() { return 3.4028234663852886e38; } // Float/MAX_VALUE, core.clj:25
     __device__ static inline double pi() { return 3.141592653589793; }
     __device__ static inline double sqrt_(double x) { return rt_sqrt(x); }
@@ -349,6 +388,7 @@ template <typename R> __device__ inline void rand_in_unit_sphere_wave(Path<R> &P
         if (pending) {
             x = next_symmetric(P); y = next_symmetric(P); z = next_symmetric(P);
             pending = dot3(x, y, z, x, y, z) >= R(1.0);
+            RTMI_PH(PH_SAMPLER)
         }
     }
     u64 rem = __ballot(pending);
@@ -376,6 +416,7 @@ template <typename R> __device__ inline void rand_in_unit_sphere_wave(Path<R> &P
             P.ctr += used;
             if (mine) { x = fx; y = fy; z = fz; pending = false; }
         }
+        RTMI_PH(PH_SAMPLER) // a cooperative round: every lane evaluates a candidate
         rem = __ballot(pending);
     }
 #else
@@ -770,6 +811,9 @@ __device__ inline void scan_all_cull(SceneRef sc, const Path<double> &P, double 
 // ---- RTMI_ACCEL_BVH: per-lane BVH traversal with conservative float boxes, exact FP64 leaves -------------------------
 // Closest hit is order independent: candidate(prim) = first root if > t-min else second root (hitable.clj:192-207 with the
 // running t-max of hitable.clj:20 only ever rejecting non-minimal candidates); ties -> lowest Hitlist index (first wins).
+#ifndef RTMI_EXIT_IBALLOT
+#define RTMI_EXIT_IBALLOT 1
+#endif
 #define RTMI_BVH_EMPTY ((int)0x80000000) // no child / traversal done; negative like the leaf codes, so "inner node" is one sign test (a leaf code ~(idx | moving << 30) never equals it)
 #ifndef RTMI_BVH_STACK
 #define RTMI_BVH_STACK 32
@@ -845,6 +889,7 @@ __device__ inline bool slab_hit(const v2f a, const v2f b, const v2f z, const flo
     return tn <= tf;
 }
 
+__device__ inline float min_raw(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ inline float float_up(double x) { // smallest float >= x (x finite, |x| < FLT_MAX)
     float f = (float)x;
     if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + (f >= 0.0f ? 1u : (unsigned)-1));
@@ -893,12 +938,7 @@ __device__ inline BvhRay make_bvh_ray(SceneRef sc, const Path<R> &P, R a, R tmin
 // column per thread (stack[level * blockDim.x + tid]: conflict-free).  leaf(code) runs the exact test, best() returns the
 // current float upper bound of the closest t.
 #ifdef RTMI_STAMPS // diagnostic build only (make stamps)
-__device__ unsigned long long g_stamps[16], g_stamps2[8];
-__device__ inline unsigned long long stamp_now() {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-}
+__device__ unsigned long long g_phase[48]; // [0..15] wave ticks per phase, [16..31] lane-ticks, [32..47] stamps executed, summed over the launch's waves
 #endif
 // Where a lane's traversal stands: node = the node to visit next (inner node: byte offset of its record (>= 0); leaf: ~(primitive |
 // moving << 30) (< 0); RTMI_BVH_EMPTY: done), tos = the newest stack entry (a register), top = next free slot of the thread's LDS column.
@@ -929,7 +969,14 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, const BvhRay &r, BvhCursor 
         { const int c = __popcll(__ballot(1)); if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_hist[128 + c], 1ull); }
 #endif
         bool descend = node >= 0;
+#ifdef RTMI_STAMPS
+        RTMI_PH(PH_BVH_POST) // loop control between the phases
+        unsigned st_trips = 0, st_lane_trips = 0;
+#endif
         while (descend) { // inner node: both child boxes come with it (one record)
+#ifdef RTMI_STAMPS
+            st_trips += 1; st_lane_trips += (unsigned)__popcll(__ballot(1));
+#endif
 #ifdef RTMI_HIST
             { const int c = __popcll(__ballot(1)); if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_hist[c], 1ull); }
 #endif
@@ -947,8 +994,9 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, const BvhRay &r, BvhCursor 
                 // hit  <=>  max(entry distances, t-min) <= min(exit distances, best t so far)
                 tl = fmaxf(fmaxf(fmaf((float)lx.x, r.ixy.x, r.cex), fmaf((float)ly.x, r.ixy.y, r.cey)), fmaxf(fmaf((float)lz.x, r.izz.x, r.cez), r.tmin_lo));
                 tr = fmaxf(fmaxf(fmaf((float)rx.x, r.ixy.x, r.cex), fmaf((float)ry.x, r.ixy.y, r.cey)), fmaxf(fmaf((float)rz.x, r.izz.x, r.cez), r.tmin_lo));
-                const float fl = fminf(fminf(fmaf((float)lx.y, r.ixy.x, r.cxx), fmaf((float)ly.y, r.ixy.y, r.cxy)), fminf(fmaf((float)lz.y, r.izz.x, r.cxz), best_hi));
-                const float fr = fminf(fminf(fmaf((float)rx.y, r.ixy.x, r.cxx), fmaf((float)ry.y, r.ixy.y, r.cxy)), fminf(fmaf((float)rz.y, r.izz.x, r.cxz), best_hi));
+                // (min_raw: best_hi is loop-carried, so the compiler would re-quiet it with a v_max x, x before every fminf -- it is never a NaN)
+                const float fl = fminf(fminf(fmaf((float)lx.y, r.ixy.x, r.cxx), fmaf((float)ly.y, r.ixy.y, r.cxy)), min_raw(fmaf((float)lz.y, r.izz.x, r.cxz), best_hi));
+                const float fr = fminf(fminf(fmaf((float)rx.y, r.ixy.x, r.cxx), fmaf((float)ry.y, r.ixy.y, r.cxy)), min_raw(fmaf((float)rz.y, r.izz.x, r.cxz), best_hi));
                 hl = tl <= fl; hr = tr <= fr;
                 cl = (int)n1.z; cr = (int)n1.w;
             } else { // 64-byte record: l.lo.xy l.hi.xy | r.lo.xy r.hi.xy | l.lo.z l.hi.z r.lo.z r.hi.z | left, right
@@ -972,7 +1020,17 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, const BvhRay &r, BvhCursor 
             descend = node >= 0;
             // time-sliced: the few lanes on long descents stop holding up the lanes that wait with a leaf (one exit condition per lane:
             // a wave-uniform `break` costs the structured loop a dozen scalar instructions per trip)
+#if RTMI_EXIT_IBALLOT
+            if (SLICE) { // the lane mask of the descending lanes IS the loop's next exec mask: no second compare to turn it back into a per-lane flag
+                const unsigned long long dm = __ballot(descend);
+                descend = __builtin_amdgcn_inverse_ballot_w64(__popcll(dm) >= min_lanes ? dm : 0ull);
+            }
+#else
             if (SLICE) descend = descend & (__popcll(__ballot(descend)) >= min_lanes);
+#endif
+#ifdef RTMI_STAMPS
+            if (__ballot(descend) == 0) { RTMI_PH_LANES(PH_DESCENT, st_lane_trips, st_trips) } // the wave's last trip: these lanes were in every trip
+#endif
         }
         if (node < 0 && node != RTMI_BVH_EMPTY) { // leaf: one primitive, exact FP64 test
 #ifdef RTMI_HIST
@@ -982,6 +1040,7 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, const BvhRay &r, BvhCursor 
             leaf(node);
             best_hi = best();
             node = tos; top -= stride; tos = *top;
+            RTMI_PH(PH_LEAF)
         }
         if (SLICE && __popcll(__ballot(node != RTMI_BVH_EMPTY)) < min_lanes) break; // wave-uniform
     }
@@ -1032,9 +1091,11 @@ __device__ inline bool scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, 
         cur = bvh_cursor_at_root(sc, stack);
     }
     const Quot<R> qa = make_quot<R>(a, tmin, best_t); // every root of this ray divides by a
+    RTMI_PH(PH_BVH_SETUP)
     if (!(SLICE && resume)) { // 1. the big primitives (sky dome, ground, ...): exact test, ascending Hitlist index
         if (COUNT) cnt[1] += (unsigned)sc.n_big;
         for (int k = 0; k < sc.n_big; ++k) exact_prim_test<R>(exact12, sc.big_idx[k], sc.big_idx[k], P, qa, tmin, behind_ok, best_t, best_i);
+        RTMI_PH(PH_BIG)
     }
     // 2. the tree
     auto leaf = [&](int code) { exact_prim_test_lane<R>(exact12, code, P, qa, tmin, behind_ok, best_t, best_i); };
@@ -1314,6 +1375,10 @@ template <typename R> struct HitRec { R t, px, py, pz, nx, ny, nz, u, v; int ori
 // tex_kind = RTMI_TEX_CHECKER2 (record-only code): a Checkerboard of two Constant textures -- the two colours and the scale are in
 // the record as well (r,g,b = tex0 = the colour where the sine product is negative; c1 = tex1), texture.clj:44-50.
 #define RTMI_TEX_CHECKER2 100
+// tex_kind = RTMI_TEX_GRADIENT_REC (record-only code): a UVGradient (texture.clj:26-34) -- e.g. the cover scene's sky dome, a third of all
+// segments end on it -- whose twelve parameters sit in mat_grad[material]: one address, known with the material index, instead of the
+// chain material -> texture index -> tex_kind -> tex_param
+#define RTMI_TEX_GRADIENT_REC 101
 // Dielectric: inv_ri = 1/ri (shader.clj:89) and r0 = ((1-ri)/(1+ri))^2 (schlick, shader.clj:71-72) depend on the material only: the
 // host evaluates the same IEEE operations once per material instead of two FP64 divisions per scatter (FP64 kernels; RTMI_F32 evaluates
 // them in float as before)
@@ -1342,8 +1407,10 @@ template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path
     if (len > R(0)) { const R inv = R(1.0) / len; nx = nx * inv; ny = ny * inv; nz = nz * inv; }
     h.nx = nx; h.ny = ny; h.nz = nz;
     h.u = R(0); h.v = R(0);
+    RTMI_PH(PH_HITREC)
     if (h.kind == RTMI_PRIM_UVSPHERE && (all_uv || (kind_flags & RTMI_PRIM_NEEDS_UV))) {
         Real<R>::sphere_uv(nx, ny, nz, &h.u, &h.v);
+        RTMI_PH(PH_UV)
     }
 }
 
@@ -1431,27 +1498,31 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
     if (is_metal || is_diel) {
         dmag = Real<R>::sqrt_(dot3(ux, uy, uz, ux, uy, uz));
         if (dmag > R(0)) { const R inv = R(1.0) / dmag; ux = ux * inv; uy = uy * inv; uz = uz * inv; }
+        RTMI_PH(PH_DNORM)
     }
     // phase 2 -- rand-in-unit-sphere: Lambertian (shader.clj:32) and Metal (shader.clj:53; drawn even when fuzz = 0)
     R rx = R(0), ry = R(0), rz = R(0);
-    RTMI_SUBSTAMP(9)
+    RTMI_PH(PH_DIRS) // (the material record fetch and the flags)
     rand_in_unit_sphere_wave(P, is_lamb || is_metal || is_iso, rx, ry, rz);
-    RTMI_SUBSTAMP(10)
+    RTMI_PH(PH_SAMPLER)
     // phase 3 -- directions
     if (is_lamb) { // shader.clj:29-34: target = (p + normal) + rand; dir = target - p
         const R tx = (px + nx) + rx, ty = (py + ny) + ry, tz = (pz + nz) + rz;
         sdx = tx - px; sdy = ty - py; sdz = tz - pz;
         scat = true;
+        RTMI_PH(PH_DIRS)
     } else if (is_iso) { // (ray p (rand-in-unit-sphere) t): the scattered ray's TIME is the hit's t (shader.clj:136)
         sdx = rx; sdy = ry; sdz = rz;
         P.time = h.t;
         scat = true;
+        RTMI_PH(PH_DIRS)
     } else if (is_metal) { // shader.clj:46-57 + reflect shader.clj:6-9
         const R fuzz = mparam;
         const R k = R(2.0) * dot3(ux, uy, uz, nx, ny, nz);
         const R rfx = ux - k * nx, rfy = uy - k * ny, rfz = uz - k * nz;
         sdx = rfx + fuzz * rx; sdy = rfy + fuzz * ry; sdz = rfz + fuzz * rz;
         scat = dot3(sdx, sdy, sdz, nx, ny, nz) > R(0);
+        RTMI_PH(PH_DIRS)
     } else if (is_diel) { // shader.clj:76-102, refract 11-20, schlick 69-74
         const R ri = mparam;
         const R dn = dot3(P.dx, P.dy, P.dz, nx, ny, nz);
@@ -1476,8 +1547,8 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
             }
         }
         scat = true;
+        RTMI_PH(PH_DIRS)
     }
-    RTMI_SUBSTAMP(11)
     // phase 4 -- ONE texture evaluation: emitted of DiffuseLight (shader.clj:118-119) or the albedo of a successful
     // Lambertian / Metal scatter (shader.clj:34,57)
     if (is_light || is_lamb || is_iso || (is_metal && scat)) {
@@ -1489,11 +1560,18 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
             const int sx = sin_sign<R>(scale * px), sy = sin_sign<R>(scale * py), sz = sin_sign<R>(scale * pz);
             const bool neg = sx * sy * sz < 0;
             tr = neg ? (R)m1.y : (R)m3.y; tg = neg ? (R)m2.x : (R)m4.x; tb = neg ? (R)m2.y : (R)m4.y;
+        } else if (mtk == RTMI_TEX_GRADIENT_REC) { // the operations of tex_sample's UVGradient case, operands from the material's second record
+            const double2 *gq = reinterpret_cast<const double2 *>(sc.mat_grad + (size_t)mat * 12);
+            const double2 g0 = gq[0], g1 = gq[1], g2 = gq[2], g3 = gq[3], g4 = gq[4], g5 = gq[5]; // co.rg co.b|cu.r cu.gb cv.rg cv.b|cuv.r cuv.gb
+            const R u = h.u, v = h.v, omu = R(1.0) - u, omv = R(1.0) - v;
+            const R a0 = (R)g1.y * omu + (R)g0.x * u, a1 = (R)g2.x * omu + (R)g0.y * u, a2 = (R)g2.y * omu + (R)g1.x * u;
+            const R b0 = (R)g4.y * omu + (R)g3.x * u, b1 = (R)g5.x * omu + (R)g3.y * u, b2 = (R)g5.y * omu + (R)g4.x * u;
+            tr = b0 * omv + a0 * v; tg = b1 * omv + a1 * v; tb = b2 * omv + a2 * v;
         } else tex_sample<R, F4>(sc, mtex, h.u, h.v, px, py, pz, tr, tg, tb);
         if (is_light) { emit[0] = R(0) + P.ar * tr; emit[1] = R(0) + P.ag * tg; emit[2] = R(0) + P.ab * tb; } // core.clj:37-39: (add accum (mul atten emitted))
         else { atr = tr; atg = tg; atb = tb; }
+        RTMI_PH(PH_TEXTURE)
     }
-    RTMI_SUBSTAMP(12)
     if (!scat) return false;
     if (att) { att[0] = atr; att[1] = atg; att[2] = atb; }
     // recur: scattered ray (time inherited), depth-1, atten*attenuation; accum unchanged (emitted of these is 0)
@@ -1512,9 +1590,10 @@ __device__ inline bool shade_segment(SceneRef sc, Path<R> &P, R t, int orig, Seg
     if (!passenger && orig < 0) return false; // miss: (color) returns accum, core.clj:40-41
     HitRec<R> h;
     h.px = h.py = h.pz = h.nx = h.ny = h.nz = h.u = h.v = h.t = R(0); h.mat = 0; h.orig = 0; h.kind = 0;
-    RTMI_SUBSTAMP(-1)
-    if (!passenger) resolve_any<R, EXT>(sc, P, t, orig, h, false);
-    RTMI_SUBSTAMP(8)
+    if (!passenger) {
+        resolve_any<R, EXT>(sc, P, t, orig, h, false);
+        RTMI_PH(PH_HITREC)
+    }
     const bool scat = scatter_emit<R, EXT>(sc, P, h, nullptr, emit, passenger);
     if (lg && lg->n < lg->max_seg) {
         double *q = lg->rec + (size_t)lg->n * RTMI_SEG_REC;

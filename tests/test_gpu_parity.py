@@ -76,15 +76,15 @@ def _ulp_gap(x, ref):
 
 
 def test_sqrt_fast_and_libm_paths_are_correctly_rounded():
-    """rt_sqrt: a wave whose arguments are all finite and >= 2^-767 takes the bare Goldschmidt core, any other wave the libm sequence;
-    both must return the correctly rounded root (= numpy's) -- waves of 64 consecutive probe threads are built to take each path"""
+    """rt_sqrt: a lane whose argument is finite and >= 2^-767 takes the bare Goldschmidt core, any other lane the libm sequence (the choice is
+    per lane); both must return the correctly rounded root (= numpy's) -- waves with all, one and no lane on the libm path"""
     rng = np.random.default_rng(5)
     n = 64 * 600
     normal = np.abs(rng.normal(0, 1, n)) * 10.0 ** rng.integers(-12, 12, n) + 1e-300  # every wave: fast path
     edge = np.array([2.0 ** -767, np.nextafter(2.0 ** -767, 1.0), 1.7976931348623157e308, 4.0, 2.0, 1.0 + 2 ** -52, 1e-200, 1e200] * 8)
     specials = np.array([0.0, -0.0, np.inf, np.nan, -1.0, 5e-324, 2.2250738585072014e-308, np.nextafter(2.0 ** -767, 0.0)] * 8)
     mixed = normal[: 64 * 100].copy()
-    mixed[::64] = np.resize(specials, 100)  # one lane per wave forces the libm path for the other 63 too
+    mixed[::64] = np.resize(specials, 100)  # one lane per wave on the libm path, the other 63 on the core
     tiny = np.abs(rng.normal(0, 1, 64 * 50)) * 10.0 ** rng.integers(-320, -240, 64 * 50).astype(np.float64)
     a = np.concatenate([normal, edge, mixed, specials, tiny])
     abc = np.stack([a, np.ones_like(a), np.zeros_like(a)], axis=1)
@@ -142,14 +142,21 @@ def test_per_ray_reciprocal_division():
     num = rng.normal(0, 1, n) * 10.0 ** rng.integers(-12, 13, n)
     o = core.probe_math(np.stack([num, a, np.zeros(n)], axis=1))
     assert np.all(o[:, 7] == 1.0) and np.array_equal(o[:, 5], num / a)
-    # one lane with a out of range (or a t-min of 0, or an unbounded t-max) sends its whole wave to the plain division: same bits again
+    # the choice is PER LANE (a ray's roots never depend on its wave-mates): a lane whose a is out of range takes the plain division,
+    # the other 63 lanes of its wave keep the reciprocal form -- the IEEE quotient in every lane either way
     a2 = a.copy()
     a2[::128] = np.resize([1e-80, 1e80, 0.0, np.inf, np.nan, 5e-324], len(a2[::128]))
     o = core.probe_math(np.stack([num, a2, np.zeros(n)], axis=1))
     with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
         ref = num / a2
-    flag = o[:, 7].reshape(-1, 64)
-    assert np.all(flag[::2] == 0.0) and np.all(flag[1::2] == 1.0) and np.array_equal(o[:, 5], ref, equal_nan=True)
+    slow = np.zeros(n, bool)
+    slow[::128] = True
+    assert np.all(o[slow, 7] == 0.0) and np.all(o[~slow, 7] == 1.0) and np.array_equal(o[:, 5], ref, equal_nan=True)
+    # hard-to-round quotients: n = q a (1 + k 2^-53) around exact products, where a faithfully rounded quotient would miss the IEEE one
+    q = rng.uniform(1.0, 2.0, n)
+    hard = (q * a) * (1.0 + rng.integers(-3, 4, n) * 2.0 ** -53)
+    o = core.probe_math(np.stack([hard, a, np.zeros(n)], axis=1))
+    assert np.all(o[:, 7] == 1.0) and np.array_equal(o[:, 5], hard / a)
     for tmin, tmax in ((0.0, 3.4e38), (-1.0, 3.4e38), (0.001, np.inf), (0.001, 1e300)):
         o = core.probe_math(np.stack([num, a, np.zeros(n)], axis=1), tmin=tmin, tmax=tmax)
         assert np.all(o[:, 7] == 0.0) and np.array_equal(o[:, 5], num / a)

@@ -1,0 +1,289 @@
+"""GPU tests added in round 3: the in-library RCCL gather executed on the hardware that exists (a one-rank communicator), which gather
+ran, the error path of the multi-device entry, back-to-back asynchronous frames, the sample-buffer budget under memory pressure,
+BASELINE's C4 at full size, a many-pass C5, the traversal counters of the mixed-kind (f3 / f4) kernels.  Everything goes through the C-ABI."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import raytrace_clj_amd as r
+from raytrace_clj_amd import core
+from raytrace_clj_amd import flatten as fl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+RMS_TOL = 1e-4
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+def gather_path(ctx):
+    p = C.c_int32(-1)
+    core.check(r._ffi.lib().rtmi_last_gather_path(ctx.handle, C.byref(p)))
+    return r._ffi.GATHER_PATHS[p.value]
+
+
+def stream_idle(ctx):
+    v = C.c_int32(-1)
+    core.check(r._ffi.lib().rtmi_stream_idle(ctx.handle, C.byref(v)))
+    return bool(v.value)
+
+
+def last_passes(ctx):
+    v = C.c_int32(-1)
+    core.check(r._ffi.lib().rtmi_last_passes(ctx.handle, C.byref(v)))
+    return v.value
+
+
+# ---- the RCCL branch of rtmi_render_multi_device, on one GPU ------------------------------------------------------------------------
+def test_rccl_gather_one_rank_communicator(cover11, monkeypatch):
+    """RTMI_MULTI_GATHER=rccl with ONE replica runs the whole in-library RCCL path -- dlopen of librccl (in this process: the copy PyTorch
+    already maps), the six entry points, ncclCommInitAll over one device, ncclGroupStart / in-place ncclGather / ncclGroupEnd on the
+    context stream, assemble -- which a one-GPU host otherwise never reaches.  Image and counters equal rtmi_render's; the context
+    reports the path that ran.  (A communicator over several devices needs several devices: not on this pool.)"""
+    from raytrace_clj_amd import dist as rdist
+    nx, ny, ns = 200, 100, 8
+    flat = fl.flatten(cover11)
+    ds = core.DeviceScene(flat)
+    lin, q, cnt = ds.render(nx, ny, ns)
+    ds.close()
+    monkeypatch.setenv("RTMI_MULTI_GATHER", "rccl")
+    one = rdist.MultiDevice(flat, [0])
+    for _ in range(3):  # the communicator is created once and kept
+        mlin, mq, mcnt = one.render(nx, ny, ns)
+        assert np.array_equal(mlin, lin) and np.array_equal(mq, q) and np.array_equal(mcnt, cnt)
+        assert gather_path(one.ctxs[0]) == "rccl"
+    assert one.last_gather_ms() >= 0.0
+    one.close()
+    # RCCL refuses one device twice in a communicator: forcing it onto replicas that share a device is an argument error, not a substitution
+    two = rdist.MultiDevice(flat, [0, 0])
+    with pytest.raises(core.RtmiError) as e:
+        two.render(nx, ny, ns)
+    assert e.value.code == -1 and "distinct devices" in str(e.value)
+    monkeypatch.delenv("RTMI_MULTI_GATHER")
+    mlin, mq, mcnt = two.render(nx, ny, ns)  # the same replicas, default policy: device copies
+    assert np.array_equal(mlin, lin) and np.array_equal(mcnt, cnt) and gather_path(two.ctxs[0]) == "same-device"
+    two.close()
+    plain = rdist.MultiDevice(flat, [0])
+    plain.render(nx, ny, ns)
+    assert gather_path(plain.ctxs[0]) == "none"
+    plain.close()
+
+
+def test_rccl_unusable_is_an_error_when_forced_not_a_substitution(tmp_path):
+    """RTMI_MULTI_GATHER=rccl with an RCCL that cannot be opened ($RTMI_RCCL_LIB names a missing library): the call fails with the loader's
+    message (the path that used to dereference dlerror()'s second, NULL, result) -- in a process of its own, because the library gives up
+    on RCCL for the rest of the process once it could not be opened."""
+    code = (
+        "import numpy as np, raytrace_clj_amd as r\n"
+        "from raytrace_clj_amd import core, flatten as fl, dist as rdist\n"
+        "flat = fl.flatten(r.scene.make_random_scene(200, 100, 3, False))\n"
+        "md = rdist.MultiDevice(flat, [0])\n"
+        "try:\n"
+        "    md.render(64, 32, 2)\n"
+        "    print('NO ERROR')\n"
+        "except core.RtmiError as e:\n"
+        "    print('ERR', e.code, str(e))\n"
+    )
+    env = dict(os.environ, RTMI_MULTI_GATHER="rccl", RTMI_RCCL_LIB="librccl_does_not_exist.so.1", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ERR -2" in out.stdout and "dlopen(librccl_does_not_exist.so.1)" in out.stdout, out.stdout + out.stderr
+
+
+def test_torch_free_c_host_runs_the_rccl_gather(tmp_path):
+    """tests/host_smoke.c with RTMI_MULTI_GATHER=rccl: a process that has never seen torch opens /opt/rocm's librccl.so.1 by soname, binds
+    the entry points and runs the one-rank gather (third frame of its output) -- what a JVM host would load."""
+    z = np.load(os.path.join(GOLD, "render_cover_n3.npz"))
+    exe = tmp_path / "host_smoke"
+    subprocess.run(["gcc", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", str(exe), os.path.join(ROOT, "tests", "host_smoke.c"), "-ldl"], check=True)
+    nx, ny = int(z["nx"]), int(z["ny"])
+    with open(tmp_path / "scene.bin", "wb") as f:
+        f.write(np.array([len(z["prim_kind"]), len(z["mat_kind"]), len(z["tex_kind"]), int(z["cam_kind"]), nx, ny, int(z["ns"]), int(z["depth"])], np.int32).tobytes())
+        f.write(np.array([int(z["seed"])], np.uint64).tobytes())
+        for k, dt in (("prim_kind", np.int32), ("prim_geom", np.float64), ("prim_mat", np.int32), ("mat_kind", np.int32), ("mat_tex", np.int32),
+                      ("mat_param", np.float64), ("tex_kind", np.int32), ("tex_param", np.float64), ("tex_child", np.int32), ("cam", np.float64)):
+            f.write(np.ascontiguousarray(z[k], dt).tobytes())
+    env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "LD_PRELOAD")}
+    env["RTMI_HOST_SMOKE_RCCL"] = "1"
+    out = subprocess.run([str(exe), r._ffi.LIB_PATH, str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rccl probe ok" in out.stdout and "gather path of the one-rank frame: 3" in out.stdout, out.stdout + out.stderr
+    raw = open(tmp_path / "out.bin", "rb").read()
+    n = nx * ny * 3
+    one = n * 8 + n + 16
+    assert len(raw) == 3 * one
+    blob = raw[2 * one:]
+    lin = np.frombuffer(blob[:n * 8], np.float64).reshape(ny, nx, 3)
+    cnt = np.frombuffer(blob[n * 8 + n:], np.uint64)
+    assert rms(lin, z["linear"]) < 1e-13 and np.array_equal(cnt, z["counters"])
+
+
+# ---- error path: a replica fails after earlier replicas were launched -------------------------------------------------------------------
+def test_multi_device_error_leaves_no_work_in_flight(cover11):
+    """replica 2's render fails (test hook) after replicas 0 and 1 have been enqueued: the call returns the error only once every stream
+    it touched is idle (the caller may destroy the contexts next), and the replicas render correctly afterwards"""
+    import torch
+    from raytrace_clj_amd import dist as rdist
+    nx, ny, ns = 800, 400, 64  # ~1 ms per replica: long enough to still be running when the failing replica returns
+    flat = fl.flatten(r.scene.make_random_scene(nx, ny, 11, False))
+    ds = core.DeviceScene(flat)
+    lin, q, cnt = ds.render(nx, ny, ns)
+    ds.close()
+    md = rdist.MultiDevice(flat, [0, 0, 0])
+    dl = torch.zeros((ny, nx, 3), dtype=torch.float64, device="cuda")
+    dc = torch.zeros(2, dtype=torch.int64, device="cuda")
+    md.render_device(nx, ny, ns, dl, None, dc)  # workspaces allocated
+    md.sync()
+    for victim in (2, 1):
+        md.ctxs[victim].set_option("test_fail_next_render", 1)
+        with pytest.raises(core.RtmiError) as e:
+            md.render_device(nx, ny, ns, dl, None, dc)
+        assert e.value.code == -2 and "test hook" in str(e.value)
+        assert all(stream_idle(c) for c in md.ctxs), "streams must be idle when the error is returned"
+    md.render_device(nx, ny, ns, dl, None, dc)
+    md.sync()
+    assert np.array_equal(dl.cpu().numpy(), lin) and [int(dc[0]), int(dc[1])] == [int(cnt[0]), int(cnt[1])]
+    md.close()
+
+
+def test_back_to_back_async_multi_frames_do_not_overwrite_each_other():
+    """rtmi_render_multi_device is asynchronous: frame k+1's render into a replica's record must wait for frame k's copy out of it (the copy
+    runs on replica 0's stream).  Six frames with six seeds, enqueued without a host synchronisation, each into its own output."""
+    import torch
+    from raytrace_clj_amd import dist as rdist
+    nx, ny, ns = 400, 200, 16
+    flat = fl.flatten(r.scene.make_random_scene(nx, ny, 11, False))
+    seeds = [0x5EED0002 + 977 * k for k in range(6)]
+    ds = core.DeviceScene(flat)
+    want = [ds.render(nx, ny, ns, seed=s)[0] for s in seeds]
+    ds.close()
+    md = rdist.MultiDevice(flat, [0, 0, 0, 0])
+    outs = [torch.zeros((ny, nx, 3), dtype=torch.float64, device="cuda") for _ in seeds]
+    torch.cuda.synchronize()
+    for s, o in zip(seeds, outs):
+        md.render_device(nx, ny, ns, o, None, None, seed=s)
+    md.sync()
+    for k, (o, w) in enumerate(zip(outs, want)):
+        assert np.array_equal(o.cpu().numpy(), w), "frame %d" % k
+    md.close()
+
+
+# ---- the sample-buffer budget ---------------------------------------------------------------------------------------------------------
+def test_sample_buffer_allocation_failure_means_more_passes_not_an_error(cover11):
+    """the per-sample colour buffer: when its allocation fails the render halves the pass and retries (test hook: the next two allocations
+    fail), and the image does not depend on the split"""
+    nx, ny, ns = 320, 160, 64
+    flat = fl.flatten(cover11)
+    ctx = core.Context(0, timing=True)
+    ds = core.DeviceScene(flat, ctx=ctx)
+    base = ds.render(nx, ny, ns)
+    assert last_passes(ctx) == 1
+    ds.close(); ctx.close()
+    ctx = core.Context(0, timing=True)
+    ds = core.DeviceScene(flat, ctx=ctx)
+    ctx.set_option("test_fail_allocs", 2)
+    again = ds.render(nx, ny, ns)
+    assert last_passes(ctx) == 4 and ctx.last_trace_ms()[1] == 4
+    for x, y in zip(base, again):
+        assert np.array_equal(x, y)
+    ctx.set_option("test_fail_allocs", 64)  # nothing can be allocated at all: the error surfaces, as RTMI_E_NOMEM
+    ds2 = core.DeviceScene(flat, ctx=ctx)
+    ctx.set_option("workspace_bytes", 1 << 40)
+    with pytest.raises(core.RtmiError) as e:
+        ds2.render(nx * 2, ny * 2, ns)  # a larger frame: the buffer has to grow
+    assert e.value.code == -4
+    ctx.set_option("test_fail_allocs", 0)
+    ok = ds2.render(nx, ny, ns)
+    assert np.array_equal(ok[0], base[0])
+    ds2.close(); ds.close(); ctx.close()
+
+
+def test_sample_buffer_budget_follows_free_hbm():
+    """a host that holds most of the HBM itself (here: one torch tensor) still gets its frame: the budget is clamped to what is free, the
+    frame takes more passes, the image is the same"""
+    import torch
+    nx, ny, ns = 1920, 1080, 64  # 49.8 MB per sample: 3.2 GB in one pass
+    flat = fl.flatten(r.scene.make_random_scene(nx, ny, 11, False))
+    ctx = core.Context(0)
+    ds = core.DeviceScene(flat, ctx=ctx)
+    base = ds.render(nx, ny, ns)
+    assert last_passes(ctx) == 1
+    ds.close(); ctx.close()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    leave = 2 << 30
+    hog = torch.empty(int(free - leave), dtype=torch.uint8, device="cuda")
+    try:
+        ctx = core.Context(0)
+        ds = core.DeviceScene(flat, ctx=ctx)
+        lin, q, cnt = ds.render(nx, ny, ns)
+        passes = last_passes(ctx)
+        ds.close(); ctx.close()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    assert passes >= 2, passes
+    assert np.array_equal(lin, base[0]) and np.array_equal(q, base[1]) and np.array_equal(cnt, base[2])
+
+
+# ---- BASELINE configs[3] at full size ---------------------------------------------------------------------------------------------------
+def test_config_c4_full_size(oracle):
+    """BASELINE configs[3]: 3840x2160x512spp, cover scene n=11, on ONE GPU at the full sample count: determinism, sample-pass split
+    invariance (2 passes by default, 7 through a 16 GiB budget), an 8x4 oracle region at 512 spp that is also the crop of the frame, and the
+    frame dealt over 8 replicas (the 8-GPU partition, replicas sharing this GPU: device-copy gather) with counters summed.  What stays
+    untested here is only the xGMI gather between distinct devices."""
+    from raytrace_clj_amd import dist as rdist
+    nx, ny, ns = 3840, 2160, 512
+    flat = fl.flatten(r.scene.make_random_scene(nx, ny, 11, False))
+    ctx = core.Context(0)
+    ds = core.DeviceScene(flat, ctx=ctx)
+    base, q, cnt = ds.render(nx, ny, ns)
+    p_default = last_passes(ctx)
+    ctx.set_option("workspace_bytes", 16 << 30)
+    split, q2, cnt2 = ds.render(nx, ny, ns)
+    p_split = last_passes(ctx)
+    assert p_default < p_split and p_split >= 6, (p_default, p_split)
+    assert np.array_equal(base, split) and np.array_equal(q, q2) and np.array_equal(cnt, cnt2), "deterministic, whatever the pass split"
+    assert cnt[1] == nx * ny and 1.5 * nx * ny * ns < cnt[0] < 6 * nx * ny * ns
+    region = (1900, 1400, 1908, 1404)
+    lin, qr, cr = ds.render(nx, ny, ns, region=region)
+    exp, eq, ecnt = oracle.render(flat, nx, ny, ns, 50, core.RENDER_SEED, region=region, nthreads=64)
+    assert rms(lin, exp) <= RMS_TOL and rms(lin, exp) < 1e-13 and np.array_equal(cr, ecnt)
+    assert np.array_equal(lin, base[1400:1404, 1900:1908])
+    ds.close(); ctx.close()
+    md = rdist.MultiDevice(flat, [0] * 8)
+    mlin, mq, mcnt = md.render(nx, ny, ns)
+    md.close()
+    assert np.array_equal(mlin, base) and np.array_equal(mq, q) and np.array_equal(mcnt, cnt)
+    assert np.isfinite(base).all() and base.min() >= 0
+
+
+def test_config_c5_many_passes(oracle):
+    """BASELINE configs[4] (1920x1080x4096spp, 80 % glass) through an 8 GiB sample buffer: 24+ sample passes with running sums carried
+    between them, equal to the default split (3 passes); one oracle region at the full 4096 spp."""
+    nx, ny, ns = 1920, 1080, 4096
+    flat = fl.flatten(r.scene.make_random_scene(nx, ny, 11, False, mix=(0.1, 0.2)))
+    ctx = core.Context(0)
+    ds = core.DeviceScene(flat, ctx=ctx)
+    base, q, cnt = ds.render(nx, ny, ns)
+    p_default = last_passes(ctx)
+    ctx.set_option("workspace_bytes", 8 << 30)
+    many, q2, cnt2 = ds.render(nx, ny, ns)
+    p_many = last_passes(ctx)
+    assert p_default <= 4 and p_many >= 24, (p_default, p_many)
+    assert np.array_equal(base, many) and np.array_equal(q, q2) and np.array_equal(cnt, cnt2)
+    assert cnt[1] == nx * ny and 2.5 * nx * ny * ns < cnt[0] < 8 * nx * ny * ns
+    region = (1000, 700, 1008, 704)
+    lin, qr, cr = ds.render(nx, ny, ns, region=region)
+    exp, eq, ecnt = oracle.render(flat, nx, ny, ns, 50, core.RENDER_SEED, region=region, nthreads=64)
+    assert rms(lin, exp) < 1e-13 and np.array_equal(cr, ecnt) and np.array_equal(lin, base[700:704, 1000:1008])
+    ds.close(); ctx.close()
