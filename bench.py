@@ -160,20 +160,41 @@ def roofline(cfg, accel, precision, n_prims, launch_s, launches_per_step, counts
         share = share * prof.get("launches_per_frame", 1) / max(1, launches_per_step)
         fp64 = prof["valu_fp64"] * share
         other = (prof["valu_total"] - prof["valu_fp64"]) * share
-        issue_cycles = fp64 * 4.0 + other * 2.0   # a wave64 instruction occupies its SIMD-32 for 2 cycles, an FP64 one for 4
-        ach = issue_cycles / launch_s / 1e9
         peak = SIMDS * CLOCK_GHZ
         traffic = int((prof["fetch_kb"] + prof["write_kb"]) * 1024 * share)
-        out.update({"bound": "valu", "achieved": round(ach, 1), "peak": peak, "unit": "G SIMD issue-cycles/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic,
+        classes = prof.get("valu_classes")
+        prices = None
+        try:
+            prices = json.load(open(os.path.join(ROOT, "profiles", "valu_prices.json")))["classes"]
+        except (OSError, ValueError, KeyError):
+            pass
+        if classes and prices:
+            # calibrated: every PMC instruction class at the issue cost measured for it on this chip (scripts/ubench/valu_cost.hip at the
+            # kernel's 4 waves per SIMD), the instructions no class names at the price of their mix
+            named = sum(classes.values())
+            cnt = dict(classes, OTHER=max(0.0, prof["valu_total"] - named))
+            cyc = {k: sum(cnt[c] * prices[c][k] for c in cnt) * share for k in ("price", "low", "high")}
+            ach = cyc["price"] / launch_s / 1e9
+            model = {"per_class_price_cycles": {c: prices[c]["price"] for c in cnt}, "instructions_per_launch": {c: round(cnt[c] * share) for c in cnt},
+                     "frac_low": round(cyc["low"] / launch_s / 1e9 / peak, 4), "frac_high": round(min(1.0, cyc["high"] / launch_s / 1e9 / peak), 4),
+                     "prices_source": "profiles/valu_prices.json <- profiles/round3_ubench_valu_cost.txt",
+                     "round2_model_frac": round((fp64 * 4.0 + other * 2.0) / launch_s / 1e9 / peak, 4)}
+            if prof.get("valu_active_quad_cycles"):  # the hardware's own busy time: SQ_ACTIVE_INST_VALU counts 4-cycle quanta per wave instruction in flight
+                model["sq_active_inst_valu_frac"] = round(prof["valu_active_quad_cycles"] * 4.0 * share / (SIMDS * launch_s * CLOCK_GHZ * 1e9), 4)
+        else:  # profiles taken before round 3 hold no per-class counts: the FMA-calibrated two-price model (FP64 x 4, everything else x 2)
+            ach = (fp64 * 4.0 + other * 2.0) / launch_s / 1e9
+            model = {"note": "no per-class counts in this profile: FP64 x 4 + other x 2 cycles"}
+        out.update({"bound": "valu", "achieved": round(ach, 1), "peak": peak, "unit": "G SIMD issue-cycles/s", "frac": round(min(1.0, ach / peak), 4),
+                    "traffic": traffic, "issue_model": model,
                     "lanes_active": prof.get("lanes_active"),
                     "counts": {"valu_instructions_per_launch": round(prof["valu_total"] * share), "fp64_instructions_per_launch": round(fp64),
                                "fetch_kb": prof["fetch_kb"], "write_kb": prof["write_kb"], "source": prof.get("source"),
                                "kernel_sha": prof.get("kernel_sha"), "stale": prof.get("kernel_sha") != sha,
                                "note": "rocprofv3 PMC counters of this workload's trace_kernel launch (deterministic per launch), imported from "
                                        "profiles/pmc_counters.json; launch_ms is measured live (HIP events on the launch stream)"},
-                    "note": "binding resource = VALU issue under per-lane traversal divergence: frac = (FP64 instr x 4 + other VALU instr x 2 "
-                            "cycles) / (1024 SIMDs x 2.4 GHz x launch time); lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)"})
+                    "note": "binding resource = VALU issue under per-lane traversal divergence: frac = (sum over the PMC instruction classes of count x "
+                            "measured issue cost) / (1024 SIMDs x 2.4 GHz x launch time); lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): "
+                            "the share of those issue slots whose lanes do work"})
         out["hbm"]["measured_traffic_gbs"] = round(traffic / launch_s / 1e9, 2)
         out["hbm"]["measured_traffic_frac"] = round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 5)
     else:
@@ -219,6 +240,8 @@ def main():
     # RTMI_BENCH_REHEARSAL=1 (multi-process form): the ranks share GPU 0 and the gather goes through gloo on the host -- only to
     # rehearse the multi-rank control flow on a one-GPU box; never a measurement
     rehearsal = (multi_proc and os.environ.get("RTMI_BENCH_REHEARSAL") == "1") or (in_library and visible < world)
+    if in_library and not rehearsal:
+        os.environ["RTMI_MULTI_GATHER"] = "rccl"  # distinct devices: the gather is the in-library ncclGather or the run fails -- never silent peer copies
     if multi_proc and rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank if multi_proc else 0)
@@ -277,6 +300,9 @@ def main():
         def gather_ms(self):
             return self.tr.last_gather_ms() if multi_proc else None
 
+        def gather_path(self):
+            return ("host-staged gloo gather (rehearsal)" if rehearsal else "torch.distributed gather (backend nccl = RCCL)") if multi_proc else "none"
+
     class InLibrary:  # one host process, N devices behind the C-ABI
         def __init__(self, flat, nx, ny):
             devs = [i % visible for i in range(world)]
@@ -311,6 +337,9 @@ def main():
 
         def gather_ms(self):
             return self.md.last_gather_ms()
+
+        def gather_path(self):
+            return self.md.last_gather_path()
 
     def measure(drv, accel, steps, warmup, cfg_name, nx, ny, ns, n_prims, count=True):
         drv.set_option("accel", 1 if accel == "bvh" else 0)
@@ -366,6 +395,7 @@ def main():
             res["prim_tests_per_segment"] = round(counts["prim_tests"] / max(1, counts["segments"]), 3)
         if gather_ms is not None:
             res["gather_ms"] = round(gather_ms, 4)
+            res["gather_path"] = drv.gather_path()
         return res
 
     drv = InLibrary(flat, nx, ny) if in_library else OneGpu(flat, nx, ny, max(1, args.frames_in_flight) if world == 1 else 1)
@@ -383,7 +413,7 @@ def main():
                                       ("one host process, rtmi_render_multi_device (in-library ncclGather)" if in_library else "one GPU")},
             "roofline": res["roofline"],
         }
-        for k in ("aabb_tests_per_segment", "prim_tests_per_segment", "gather_ms"):
+        for k in ("aabb_tests_per_segment", "prim_tests_per_segment", "gather_ms", "gather_path"):
             if k in res:
                 out[k] = res[k]
         if world > 1:
@@ -401,7 +431,7 @@ def main():
                                 "note": "the same steps with two frames in flight on two streams: a frame's first workgroups fill the CUs the "
                                         "previous frame's last deep paths leave idle; only for hosts that render frame after frame"}
             two.pl.close()
-        for other in ("C2", "C4"):
+        for other in ("C2", "C4", "C5"):  # BASELINE configs[1], [3] (on one GPU) and [4] (the divergence-stress configuration)
             if other == cfg:
                 continue
             onx, ony, ons = CONFIGS[other][:3]
@@ -410,6 +440,9 @@ def main():
             o = measure(od, args.accel, 10 if other == "C2" else 2, 2 if other == "C2" else 1, other, onx, ony, ons, oflat.n_prims)
             out[other.lower()] = {"workload": workload_text(other, onx, ony, ons, oflat.n_prims, args.accel, 1), "value": o["value"],
                                   "ms_per_step": o["ms_per_step"], "segments_per_sample": o["segments_per_sample"], "roofline": o["roofline"]}
+            for k in ("aabb_tests_per_segment", "prim_tests_per_segment"):
+                if k in o:
+                    out[other.lower()][k] = o[k]
             od.pl.close()
         if cfg in ("C1", "C2", "C2m", "CB", "FINAL"):  # the other acceleration structure where it finishes in seconds
             other_accel = "flat" if args.accel == "bvh" else "bvh"

@@ -8,7 +8,9 @@
   caller can fall back to the protocol path (raytrace-clj.core/pixel).
 
   STATUS: written blind (no JVM/lein/JNA jar in the build container); the Python mirror in
-  raytrace_clj_amd/ exercises the same C-ABI call for call and is what the tests run."
+  raytrace_clj_amd/ exercises the same C-ABI call for call and is what the tests run.  What CAN be checked without a JVM is:
+  tests/test_clj_conformance.py reads this file's (call-int \"rtmi_...\" ...) forms against the prototypes of include/rtmi.h --
+  symbol, arity, (int ...) / (long ...) coercion of every scalar, element type of every array, handle vs handle-by-reference."
   (:require [clojure.core.matrix :as mat]
             [raytrace-clj.scene :as scene]
             [raytrace-clj.perlin :as perlin]
@@ -229,6 +231,39 @@
 ;;; render: replaces (dorun (cp/upmap ...)) of core.clj:100-108
 ;;; ---------------------------------------------------------------------------------------------
 
+(defn- create-scene!
+  "rtmi_scene_create_ex + everything a scene may need before its first render -- the namespace-level Perlin tables of the running
+  JVM (perlin.clj:6-17), the decoded ImageMap pixels (texture.clj:126-133), the media call sequence -- on context `ctx` (a Pointer).
+  Returns the scene Pointer.  Clones (rtmi_scene_clone) carry all of it."
+  [ctx f]
+  (let [scn (PointerByReference.)]
+    (check (call-int "rtmi_scene_create_ex" ctx
+                     (int (:n-prims f)) (:prim-kind f) (:prim-geom f) (:prim-mat f)
+                     (int (:n-mats f)) (:mat-kind f) (:mat-tex f) (:mat-param f)
+                     (int (:n-tex f)) (:tex-kind f) (:tex-param f) (:tex-child f)
+                     (int (:cam-kind f)) (:cam f)
+                     (:prim-flip f) (:prim-xform f) (int (:n-xforms f)) (:xform-kind f) (:xform-param f) scn))
+    (let [scene (.getValue scn)]
+      (when (:uses-perlin f)
+        (let [vectors (double-array (mapcat v3 perlin/random-vectors))
+              perm    (int-array (concat perlin/perm-x perlin/perm-y perlin/perm-z))]
+          (check (call-int "rtmi_scene_set_perlin" scene vectors perm))))
+      ;; ImageMap pixels: rows top-down, RGB (imagez get-pixel = BufferedImage.getRGB, texture.clj:76)
+      (when (seq (:images f))
+        (let [imgs (:images f)
+              wh   (int-array (mapcat (fn [^java.awt.image.BufferedImage im] [(.getWidth im) (.getHeight im)]) imgs))
+              px   (byte-array (mapcat (fn [^java.awt.image.BufferedImage im]
+                                         (for [y (range (.getHeight im)) x (range (.getWidth im))
+                                               :let [p (.getRGB im (int x) (int y))]
+                                               sh [16 8 0]]
+                                           (unchecked-byte (bit-and 0xff (bit-shift-right p sh)))))
+                                       imgs))]
+          (check (call-int "rtmi_scene_set_images" scene (int (count imgs)) wh px))))
+      (when (pos? (alength ^ints (:media-calls f)))
+        (let [calls (:media-calls f)]
+          (check (call-int "rtmi_scene_set_media_calls" scene (int (alength ^ints calls)) calls))))
+      scene)))
+
 (defn render
   "Render scene {:camera :world} at nx x ny with ns samples per pixel on GPU `device`.
   Returns {:rgb8 byte-array (row 0 = top, RGB interleaved) :linear double-array
@@ -236,76 +271,40 @@
   [scene nx ny ns & {:keys [depth seed device precision] :or {depth 50 seed 0x5eed0002 device 0 precision 0}}]
   (let [f    (flatten-scene scene)
         ctx  (PointerByReference.)
-        scn  (PointerByReference.)
         npx  (* nx ny)
         lin  (double-array (* 3 npx))
         rgb  (byte-array (* 3 npx))
         cnt  (long-array 2)]
     (check (call-int "rtmi_init" (int device) (int 0) ctx))
     (try
-      (check (call-int "rtmi_scene_create_ex" (.getValue ctx)
-                       (int (:n-prims f)) (:prim-kind f) (:prim-geom f) (:prim-mat f)
-                       (int (:n-mats f)) (:mat-kind f) (:mat-tex f) (:mat-param f)
-                       (int (:n-tex f)) (:tex-kind f) (:tex-param f) (:tex-child f)
-                       (:cam-kind f) (:cam f)
-                       (:prim-flip f) (:prim-xform f) (int (:n-xforms f)) (:xform-kind f) (:xform-param f) scn))
-      ;; the namespace-level Perlin tables of the running JVM (perlin.clj:6-17)
-      (when (:uses-perlin f)
-        (check (call-int "rtmi_scene_set_perlin" (.getValue scn)
-                         (double-array (mapcat v3 perlin/random-vectors))
-                         (int-array (concat perlin/perm-x perlin/perm-y perlin/perm-z)))))
-      ;; ImageMap pixels: rows top-down, RGB (imagez get-pixel = BufferedImage.getRGB, texture.clj:76)
-      (when (seq (:images f))
-        (let [imgs (:images f)
-              wh   (int-array (mapcat (fn [^java.awt.image.BufferedImage im] [(.getWidth im) (.getHeight im)]) imgs))
-              rgb  (byte-array (mapcat (fn [^java.awt.image.BufferedImage im]
-                                         (for [y (range (.getHeight im)) x (range (.getWidth im))
-                                               :let [p (.getRGB im (int x) (int y))]
-                                               sh [16 8 0]]
-                                           (unchecked-byte (bit-and 0xff (bit-shift-right p sh)))))
-                                       imgs))]
-          (check (call-int "rtmi_scene_set_images" (.getValue scn) (int (count imgs)) wh rgb))))
-      (when (pos? (alength ^ints (:media-calls f)))
-        (check (call-int "rtmi_scene_set_media_calls" (.getValue scn) (int (alength ^ints (:media-calls f))) (:media-calls f))))
-      (try
-        (check (call-int "rtmi_render" (.getValue scn) (int nx) (int ny) (int ns) (int depth) (long seed) (int precision)
-                         (int 0) (int 0) (int nx) (int ny) lin rgb cnt))
-        {:rgb8 rgb :linear lin :total-rays (aget cnt 0) :total-pixels (aget cnt 1)}
-        (finally (call-int "rtmi_scene_destroy" (.getValue scn))))
+      (let [scn (create-scene! (.getValue ctx) f)]
+        (try
+          (check (call-int "rtmi_render" scn (int nx) (int ny) (int ns) (int depth) (long seed) (int precision)
+                           (int 0) (int 0) (int nx) (int ny) lin rgb cnt))
+          {:rgb8 rgb :linear lin :total-rays (aget cnt 0) :total-pixels (aget cnt 1)}
+          (finally (call-int "rtmi_scene_destroy" scn))))
       (finally (call-int "rtmi_shutdown" (.getValue ctx))))))
 
 (defn render-multi
   "The same on every GPU in `devices` from this one JVM (rtmi_render_multi): one context per device, the scene created on
-  the first and cloned onto the others (rtmi_scene_clone), the 8x8 tiles of the frame dealt round-robin, ONE ncclGather
-  inside the library, assembled on the first device.  Returns what `render` returns; :total-rays is the sum over the devices.
-  The image is bit-identical to `render`'s."
+  the first (Perlin tables, ImageMap pixels and media calls included) and cloned onto the others (rtmi_scene_clone), the 8x8
+  tiles of the frame dealt round-robin, ONE ncclGather inside the library, assembled on the first device.  Returns what
+  `render` returns; :total-rays is the sum over the devices.  The image is bit-identical to `render`'s."
   [scene nx ny ns & {:keys [depth seed devices precision] :or {depth 50 seed 0x5eed0002 devices [0] precision 0}}]
   (let [f     (flatten-scene scene)
         npx   (* nx ny)
         lin   (double-array (* 3 npx))
         rgb   (byte-array (* 3 npx))
         cnt   (long-array 2)
-        ctxs  (mapv (fn [d] (let [c (PointerByReference.)] (check (call-int "rtmi_init" (int d) (int 0) c)) (.getValue c))) devices)
-        scn0  (PointerByReference.)]
+        ctxs  (mapv (fn [d] (let [ctx (PointerByReference.)] (check (call-int "rtmi_init" (int d) (int 0) ctx)) (.getValue ctx))) devices)]
     (try
-      (check (call-int "rtmi_scene_create_ex" (first ctxs)
-                       (int (:n-prims f)) (:prim-kind f) (:prim-geom f) (:prim-mat f)
-                       (int (:n-mats f)) (:mat-kind f) (:mat-tex f) (:mat-param f)
-                       (int (:n-tex f)) (:tex-kind f) (:tex-param f) (:tex-child f)
-                       (:cam-kind f) (:cam f)
-                       (:prim-flip f) (:prim-xform f) (int (:n-xforms f)) (:xform-kind f) (:xform-param f) scn0))
-      (when (:uses-perlin f)
-        (check (call-int "rtmi_scene_set_perlin" (.getValue scn0)
-                         (double-array (mapcat v3 perlin/random-vectors))
-                         (int-array (concat perlin/perm-x perlin/perm-y perlin/perm-z)))))
-      (when (pos? (alength ^ints (:media-calls f)))
-        (check (call-int "rtmi_scene_set_media_calls" (.getValue scn0) (int (alength ^ints (:media-calls f))) (:media-calls f))))
-      ;; (ImageMap pixels: as in `render`, before cloning -- the clone carries everything set on the original)
-      (let [clones (mapv (fn [c] (let [s (PointerByReference.)] (check (call-int "rtmi_scene_clone" (.getValue scn0) c s)) (.getValue s)))
+      (let [scn0   (create-scene! (first ctxs) f)
+            clones (mapv (fn [c] (let [scn (PointerByReference.)] (check (call-int "rtmi_scene_clone" scn0 c scn)) (.getValue scn)))
                          (rest ctxs))
-            scenes (into [(.getValue scn0)] clones)]
+            scenes (into [scn0] clones)
+            handles (into-array com.sun.jna.Pointer scenes)]
         (try
-          (check (call-int "rtmi_render_multi" (int (count scenes)) (into-array com.sun.jna.Pointer scenes)
+          (check (call-int "rtmi_render_multi" (int (count scenes)) handles
                            (int nx) (int ny) (int ns) (int depth) (long seed) (int precision) lin rgb cnt))
           {:rgb8 rgb :linear lin :total-rays (aget cnt 0) :total-pixels (aget cnt 1)}
           (finally (doseq [s scenes] (call-int "rtmi_scene_destroy" s)))))

@@ -124,32 +124,32 @@ __device__ inline void scan_cull_dispatch(SceneRef sc, const Path<float> &P, flo
 // hit? of the whole world for the lane's ray (closest hit, t in (t-min, t-max); core.clj:25 passes 0.001, Float/MAX_VALUE).
 // MULTI (LDS variants only): the static spheres do not fit one LDS tile; every thread of the workgroup must call this.
 // section 8(f3) scenes (FP64 only): BVH or culled flat scan over mixed primitive kinds with the any-order tie rule
-template <bool SLICED = false>
+template <bool SLICED = false, bool COUNT = false>
 __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<double> &P, bool active, double tmin, double tmax, double &best_t, int &best_i,
-                                     bool *mid = nullptr, int min_lanes = 0) {
+                                     bool *mid = nullptr, int min_lanes = 0, unsigned *cnt = nullptr) {
     best_t = tmax; best_i = -1;
     if (!active) return;
     const double a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
     ExtHit H = {tmax, 0x7fffffff, -1, false};
     if (bvh) {
         if (SLICED) { // time-sliced: a suspended lane's media are evaluated (and draw) when its traversal completes, as in the plain loop
-            const bool done = scan_bvh_ext<true>(sc, stack, P, a, tmin, H, stack + RTMI_BVH_STACK * blockDim.x, *mid, min_lanes);
+            const bool done = scan_bvh_ext<true, COUNT>(sc, stack, P, a, tmin, H, stack + RTMI_BVH_STACK * blockDim.x, *mid, min_lanes, cnt);
             *mid = !done;
             if (!done) return;
-        } else scan_bvh_ext(sc, stack, P, a, tmin, H);
+        } else scan_bvh_ext<false, COUNT>(sc, stack, P, a, tmin, H, nullptr, false, 0, cnt);
     } else scan_all_cull_ext(sc, P, a, tmin, H);
     // media: after the surfaces, in primitive-index order = the order the reference's descent calls their hit? (and draws)
-    for (int k = 0; k < sc.n_media; ++k) ext_medium_test(sc, sc.media_idx[k], P, tmin, tmax, H);
+    for (int k = 0; k < sc.n_media; ++k) ext_medium_test(sc, sc.media_idx[k], P, tmin, tmax, H, COUNT ? cnt : nullptr);
     best_i = ext_winner(H);
     if (best_i >= 0) best_t = H.t;
 }
-template <bool SLICED = false>
-__device__ inline void intersect_ext(SceneRef, int *, bool, Path<float> &, bool, float, float tmax, float &best_t, int &best_i, bool * = nullptr, int = 0) { best_t = tmax; best_i = -1; }
+template <bool SLICED = false, bool COUNT = false>
+__device__ inline void intersect_ext(SceneRef, int *, bool, Path<float> &, bool, float, float tmax, float &best_t, int &best_i, bool * = nullptr, int = 0, unsigned * = nullptr) { best_t = tmax; best_i = -1; }
 
 template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICED = false>
 __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, Path<R> &P,
                                        bool active, R tmin, R tmax, R &best_t, int &best_i, unsigned *cnt = nullptr, bool *mid = nullptr, int min_lanes = 0) {
-    if (EXT) { intersect_ext<SLICED>(sc, reinterpret_cast<int *>(lds), VARIANT == SCAN_BVH, P, active, tmin, tmax, best_t, best_i, mid, min_lanes); return; }
+    if (EXT) { intersect_ext<SLICED, COUNT>(sc, reinterpret_cast<int *>(lds), VARIANT == SCAN_BVH, P, active, tmin, tmax, best_t, best_i, mid, min_lanes, cnt); return; }
     best_t = tmax;
     best_i = -1;
     const R a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
@@ -862,7 +862,8 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         if (s->dev.has_ext) { // section 8(f3) scenes: FP64 kernels with the mixed-kind intersectors
             if (variant == SCAN_BVH) { // a Cornell box's 20-primitive tree loses 5 % to the time-slicing machinery, make-final's 3400 gain 8 %
                 const bool slice = s->bvh_node_count >= 128 && tp.suspend_lanes > 0;
-                kern = slice ? trace_kernel<double, false, SCAN_BVH, true> : trace_kernel<double, false, SCAN_BVH, true, false, false>;
+                if (c->count_traversal) kern = slice ? trace_kernel<double, false, SCAN_BVH, true, true> : trace_kernel<double, false, SCAN_BVH, true, true, false>;
+                else kern = slice ? trace_kernel<double, false, SCAN_BVH, true> : trace_kernel<double, false, SCAN_BVH, true, false, false>;
                 dyn_lds = (size_t)(RTMI_BVH_STACK + (slice ? RTMI_BVH_SUSPEND_WORDS_EXT : 0)) * kTraceBlock * sizeof(int);
             }
             else kern = trace_kernel<double, false, SCAN_SGPR_CULL, true>;
@@ -1563,17 +1564,27 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     if (!rc) rc = upload(s, stat4_f, &d.stat4_f);
     if (!rc) rc = upload(s, mov_geom, &d.mov_geom);
     if (!rc) rc = upload(s, mov_orig, &d.mov_orig);
-    { // device copy of prim_kind: + RTMI_PRIM_NEEDS_UV where a UVSphere's material texture reads uv (texture.clj: UVGradient,
-      // ImageMap, through Checkerboard / FlipTexture children); Constant, Checkerboard itself and the Perlin family read p only
-        std::vector<char> uses((size_t)std::max(n_tex, 1), 0);
+    { // device copy of prim_kind: + RTMI_PRIM_NEEDS_U / _V where a UVSphere's material texture reads that coordinate (texture.clj: UVGradient --
+      // per coordinate: a gradient whose corner colours do not vary along u never reads u --, ImageMap, through Checkerboard / FlipTexture
+      // children); Constant, Checkerboard itself and the Perlin family read p only
+        std::vector<char> uses((size_t)std::max(n_tex, 1), 0); // bit 0: reads u, bit 1: reads v
         for (int pass = 0; pass <= n_tex; ++pass) // children may come after their parents: iterate to the fixed point
             for (int t = 0; t < n_tex; ++t) {
                 const int k = tex_kind[t];
-                char u = (k == RTMI_TEX_UVGRADIENT || k == RTMI_TEX_IMAGE) ? 1 : 0;
+                char u = k == RTMI_TEX_IMAGE ? 3 : 0;
+                if (k == RTMI_TEX_UVGRADIENT) { // co cu cv cuv: a = cu (1-u) + co u, b = cuv (1-u) + cv u, out = b (1-v) + a v  (texture.clj:26-34)
+                    const double *tp = tex_param + (size_t)t * RTMI_TEX_STRIDE;
+                    bool var_u = false, var_v = false;
+                    for (int c = 0; c < 3; ++c) {
+                        var_u = var_u || !(tp[c] == tp[3 + c]) || !(tp[6 + c] == tp[9 + c]);     // co != cu or cv != cuv (NaN: keep)
+                        var_v = var_v || !(tp[c] == tp[6 + c]) || !(tp[3 + c] == tp[9 + c]);     // co != cv or cu != cuv
+                    }
+                    u = (char)((var_u ? 1 : 0) | (var_v ? 2 : 0));
+                }
                 if (k == RTMI_TEX_CHECKER || k == RTMI_TEX_FLIP_U || k == RTMI_TEX_FLIP_V)
                     for (int c = 0; c < (k == RTMI_TEX_CHECKER ? 2 : 1); ++c) {
                         const int ch = tex_child[2 * (size_t)t + c];
-                        if (ch >= 0 && ch < n_tex && uses[(size_t)ch]) u = 1;
+                        if (ch >= 0 && ch < n_tex) u |= uses[(size_t)ch];
                     }
                 uses[(size_t)t] = u;
             }
@@ -1581,7 +1592,9 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
         for (int i = 0; i < n_prims; ++i)
             if (pk[(size_t)i] == RTMI_PRIM_UVSPHERE) {
                 const int m = pm[(size_t)i], t = (m >= 0 && m < n_mats) ? mat_tex[m] : -1;
-                if (t < 0 || t >= n_tex || uses[(size_t)t]) pk_dev[(size_t)i] |= RTMI_PRIM_NEEDS_UV;
+                const int bits = (t < 0 || t >= n_tex) ? 3 : uses[(size_t)t];
+                if (bits & 1) pk_dev[(size_t)i] |= RTMI_PRIM_NEEDS_U;
+                if (bits & 2) pk_dev[(size_t)i] |= RTMI_PRIM_NEEDS_V;
             }
         if (!rc) rc = upload(s, pk_dev, &d.prim_kind);
         std::vector<int> km((size_t)std::max(n_prims, 1) * 2, 0);

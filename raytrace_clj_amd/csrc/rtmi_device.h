@@ -291,11 +291,9 @@ template <> struct Real<double> {
     __device__ static inline double sin_(double x) { return ::sin(x); }
     // get-sphere-uv (hitable.clj:128-139): u = 1 - (phi + pi) / (2 pi), v = (theta + pi/2) / pi; the two divisions by constants
     // are the correctly rounded quotients (div_const)
-    __device__ static inline void sphere_uv(double nx, double ny, double nz, double *u, double *v) {
-        const TrigTable K = trig_table();
-        *u = 1.0 - div_const(rt_atan2(nz, nx, K) + K[30], K[29], K[27]);
-        *v = div_const(rt_asin(ny, K) + K[13], K[30], K[28]);
-    }
+    __device__ static inline void sphere_uv(double nx, double ny, double nz, double *u, double *v) { *u = sphere_u(nx, nz); *v = sphere_v(ny); }
+    __device__ static inline double sphere_u(double nx, double nz) { const TrigTable K = trig_table(); return 1.0 - div_const(rt_atan2(nz, nx, K) + K[30], K[29], K[27]); }
+    __device__ static inline double sphere_v(double ny) { const TrigTable K = trig_table(); return div_const(rt_asin(ny, K) + K[13], K[30], K[28]); }
     __device__ static inline double pow_(double x, double y) { return ::pow(x, y); }
 };
 template <> struct Real<float> {
@@ -306,10 +304,9 @@ template <> struct Real<float> {
     __device__ static inline float sqrt_(float x) { return ::sqrtf(x); }
     __device__ static inline float sqrt_lib(float x) { return ::sqrtf(x); }
     __device__ static inline float sin_(float x) { return ::sinf(x); }
-    __device__ static inline void sphere_uv(float nx, float ny, float nz, float *u, float *v) {
-        *u = 1.0f - (::atan2f(nz, nx) + pi()) / (2.0f * pi());
-        *v = (::asinf(ny) + pi() / 2.0f) / pi();
-    }
+    __device__ static inline void sphere_uv(float nx, float ny, float nz, float *u, float *v) { *u = sphere_u(nx, nz); *v = sphere_v(ny); }
+    __device__ static inline float sphere_u(float nx, float nz) { return 1.0f - (::atan2f(nz, nx) + pi()) / (2.0f * pi()); }
+    __device__ static inline float sphere_v(float ny) { return (::asinf(ny) + pi() / 2.0f) / pi(); }
     __device__ static inline float pow_(float x, float y) { return ::powf(x, y); }
 };
 
@@ -1254,14 +1251,16 @@ __device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P
 // segment between them clipped to [t-min, t-max]; then ONE draw of the path's stream: hit-distance = -(log xi)/density
 // against the length of the segment decides whether (where) the ray scatters inside.  t-min/t-max are the caller's
 // un-narrowed interval, as in the reference's bvh-node descent (hitable.clj:99-105).
-__device__ inline void ext_medium_test(SceneRef sc, int idx, Path<double> &P, double tmin, double tmax, ExtHit &H) {
+__device__ inline void ext_medium_test(SceneRef sc, int idx, Path<double> &P, double tmin, double tmax, ExtHit &H, unsigned *cnt = nullptr) {
     const double FMAX = 3.4028234663852886e38;
     const size_t gi = (size_t)idx * 12; // idx comes from media_idx: wave-uniform
     const double density = ext_ld<true>(sc.exact12, gi);
     const int first = (int)ext_ld<true>(sc.exact12, gi + 1), count = (int)ext_ld<true>(sc.exact12, gi + 2);
     ExtHit h1 = {FMAX, 0x7fffffff, -1, false};
     for (int k = 0; k < count; ++k) ext_prim_test<true>(sc, first + k, P, -FMAX, h1); // idx (a medium of media_idx) is wave-uniform
+    if (cnt) cnt[1] += (unsigned)count; // exact tests of the boundary's primitives
     if (!h1.any) return;
+    if (cnt) cnt[1] += (unsigned)count;
     ExtHit h2 = {FMAX, 0x7fffffff, -1, false};
     for (int k = 0; k < count; ++k) ext_prim_test<true>(sc, first + k, P, h1.t + 0.0001, h2);
     if (!h2.any) return;
@@ -1301,9 +1300,9 @@ __device__ inline float ext_best_hi(const ExtHit &H) { return (H.t < 3.0e38 ? fl
 // Time-sliced like scan_bvh (susp: RTMI_BVH_SUSPEND_WORDS_EXT columns behind the stack; returns false when the lane's traversal was
 // suspended): the mixed-kind scenes need it most -- make-final's descent trips ran at 12.7 of 64 lanes, 66 % of them below 8.
 #define RTMI_BVH_SUSPEND_WORDS_EXT 7 // node, tos, top, H.t (2 words), H.F, H.W   (H.any <=> H.F != 0x7fffffff)
-template <bool SLICE = false>
+template <bool SLICE = false, bool COUNT = false>
 __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, ExtHit &H, int *susp = nullptr, bool resume = false,
-                                    int min_lanes = 0) {
+                                    int min_lanes = 0, unsigned *cnt = nullptr) {
     const BvhRay r = make_bvh_ray(sc, P, a, tmin);
     const int stride = blockDim.x;
     int *sw = susp + threadIdx.x;
@@ -1314,13 +1313,14 @@ __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> 
         H.t = __hiloint2double(sw[4 * stride], sw[3 * stride]);
         H.F = sw[5 * stride]; H.W = sw[6 * stride]; H.any = H.F != 0x7fffffff;
     } else {
-        if (!r.ok) { scan_all_cull_ext(sc, P, a, tmin, H); return true; }
+        if (!r.ok) { if (COUNT) cnt[1] += (unsigned)sc.n_all; scan_all_cull_ext(sc, P, a, tmin, H); return true; }
+        if (COUNT) cnt[1] += (unsigned)sc.n_big;
         for (int k = 0; k < sc.n_big; ++k) ext_prim_test<true>(sc, sc.big_idx[k], P, tmin, H);
         cur = bvh_cursor_at_root(sc, stack);
     }
     auto leaf = [&](int code) { ext_prim_test<false>(sc, (~code) & 0x3fffffff, P, tmin, H); };
     auto best = [&]() { return ext_best_hi(H); };
-    bvh_traverse<false, SLICE>(sc, r, cur, min_lanes, leaf, best);
+    bvh_traverse<COUNT, SLICE>(sc, r, cur, min_lanes, leaf, best, cnt);
     if (SLICE && cur.node != RTMI_BVH_EMPTY) { // suspended
         sw[0] = cur.node; sw[stride] = cur.tos;
         sw[2 * stride] = (int)(reinterpret_cast<char *>(cur.top) - reinterpret_cast<char *>(stack));
@@ -1328,8 +1328,10 @@ __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> 
         sw[5 * stride] = H.any ? H.F : 0x7fffffff; sw[6 * stride] = H.W;
         return false;
     }
-    if (!r.time_ok) // e.g. after Isotropic.scatter, which sets the ray's time to the hit's t (shader.clj:136)
+    if (!r.time_ok) { // e.g. after Isotropic.scatter, which sets the ray's time to the hit's t (shader.clj:136)
+        if (COUNT) cnt[1] += (unsigned)sc.n_moving_all;
         for (int k = 0; k < sc.n_moving_all; ++k) ext_prim_test<true>(sc, sc.moving_all[k], P, tmin, H);
+    }
     return true;
 }
 
@@ -1385,8 +1387,14 @@ template <typename R> struct HitRec { R t, px, py, pz, nx, ny, nz, u, v; int ori
 struct __attribute__((aligned(16))) MatRec { int mat_kind, tex, tex_kind, pad; double param, r, g, b; double scale, c1r, c1g, c1b; double inv_ri, r0; };
 
 // `all_uv`: the probes report uv of every UVSphere hit; the trace kernel computes it (atan2 + asin) only where the hit material's
-// texture reads uv (bit RTMI_PRIM_NEEDS_UV of the device copy of prim_kind: e.g. not for a constant-colour sky dome).
-#define RTMI_PRIM_NEEDS_UV 32
+// texture reads uv, and only the coordinate it reads (bits RTMI_PRIM_NEEDS_U / _V of the device copy of prim_kind): nothing for a
+// constant-colour dome; v alone (asin; no atan2) for the cover scene's sky, a UVGradient whose corner colours do not vary with u.  The
+// coordinate nobody reads is set to 0.5: the u-lerp of two EQUAL colours c (1 - u) + c u is then c exactly, where the reference's own u
+// gives c within an ulp -- a colour difference of the size the <= 2 ulp of atan2 / asin against the JVM's already allow (uv never
+// feeds geometry).
+#define RTMI_PRIM_NEEDS_U 32
+#define RTMI_PRIM_NEEDS_V 64
+#define RTMI_PRIM_NEEDS_UV (RTMI_PRIM_NEEDS_U | RTMI_PRIM_NEEDS_V)
 template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path<R> &P, R t, int orig, HitRec<R> &h, bool all_uv = true) {
     const double *g = sc.exact12 + (size_t)orig * 12;
     R cx = (R)g[0], cy = (R)g[1], cz = (R)g[2];
@@ -1409,7 +1417,9 @@ template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path
     h.u = R(0); h.v = R(0);
     RTMI_PH(PH_HITREC)
     if (h.kind == RTMI_PRIM_UVSPHERE && (all_uv || (kind_flags & RTMI_PRIM_NEEDS_UV))) {
-        Real<R>::sphere_uv(nx, ny, nz, &h.u, &h.v);
+        h.u = h.v = R(0.5);
+        if (all_uv || (kind_flags & RTMI_PRIM_NEEDS_U)) h.u = Real<R>::sphere_u(nx, nz);
+        if (all_uv || (kind_flags & RTMI_PRIM_NEEDS_V)) h.v = Real<R>::sphere_v(ny);
         RTMI_PH(PH_UV)
     }
 }

@@ -146,6 +146,13 @@ class MultiDevice:
         check(_ffi.lib().rtmi_last_gather_ms(self.ctxs[0].handle, C.byref(ms)))
         return ms.value
 
+    def last_gather_path(self):
+        """"none" | "same-device" | "peer-copy" | "rccl": how the last render moved the replicas' records to replica 0 (rtmi_last_gather_path)"""
+        import ctypes as C
+        p = C.c_int32(-1)
+        check(_ffi.lib().rtmi_last_gather_path(self.ctxs[0].handle, C.byref(p)))
+        return _ffi.GATHER_PATHS[p.value]
+
     def last_trace_ms(self):
         """per replica: (sum of trace-kernel ms, launches) since the last call"""
         return [ctx.last_trace_ms() for ctx in self.ctxs]

@@ -44,7 +44,10 @@ try:
 except (OSError, ValueError, KeyError, IndexError):
     pass
 fp64 = sum(m.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+classes = {c: m.get("SQ_INSTS_VALU_" + c) for c in ("FMA_F32", "ADD_F32", "MUL_F32", "ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "TRANS_F32", "INT32", "INT64", "CVT")}
 entry = {
+    "valu_classes": {c: v for c, v in classes.items() if v is not None},  # priced per class by bench.py (profiles/valu_prices.json)
+    "valu_active_quad_cycles": m.get("SQ_ACTIVE_INST_VALU"), "wave_quad_cycles": m.get("SQ_WAVE_CYCLES"), "branch_total": m.get("SQ_INSTS_BRANCH"),
     "valu_total": m["SQ_INSTS_VALU"], "valu_fp64": fp64, "salu_total": m.get("SQ_INSTS_SALU"), "vmem_total": m.get("SQ_INSTS_VMEM"),
     "lanes_active": round(m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_ACTIVE_INST_VALU"]), 4),
     "wave_time_share": {"issuing": round(m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"], 4), "waiting_for_issue": round(m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"], 4),

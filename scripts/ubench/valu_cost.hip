@@ -13,19 +13,19 @@ enum Op {
     OP_FMA_F32, OP_ADD_F32, OP_MUL_F32, OP_MAX3_F32, OP_MIN3_F32, OP_FMA_MIX, OP_PK_FMA_F32, OP_RCP_F32, OP_CVT_F32_F64, OP_CVT_F64_F32, OP_CVT_F64_U32,
     OP_FMA_F64, OP_ADD_F64, OP_MUL_F64, OP_RCP_F64, OP_RSQ_F64, OP_DIV_SCALE_F64, OP_DIV_FMAS_F64, OP_DIV_FIXUP_F64, OP_CMP_F64, OP_CMP_F32,
     OP_MUL_LO_U32, OP_MUL_HI_U32, OP_MAD_U64_U32, OP_ADD_U32, OP_ADDC_U32, OP_XOR_B32, OP_LSHR_B64, OP_LSHL_B64, OP_LSHR_B32, OP_ALIGNBIT, OP_CNDMASK,
-    OP_MOV_B32, OP_BFE_U32, OP_AND_OR_B32, OP_MAD_U32_U24, OP_BPERMUTE, OP_READLANE, OP_SALU_ADD, OP_VALU_SALU_MIX, OP_LDS_READ_B32, OP_LDS_WRITE_B32, OP_COUNT
+    OP_MOV_B32, OP_BFE_U32, OP_AND_OR_B32, OP_MAD_U32_U24, OP_MAX_F32, OP_CMP_F32_SGPR, OP_CVT_F32_F16, OP_ADD3_U32, OP_LSHL_ADD_U64, OP_READFIRSTLANE, OP_BPERMUTE, OP_READLANE, OP_SALU_ADD, OP_VALU_SALU_MIX, OP_LDS_READ_B32, OP_LDS_WRITE_B32, OP_COUNT
 };
 static const char *kNames[OP_COUNT] = {
     "v_fma_f32", "v_add_f32", "v_mul_f32", "v_max3_f32", "v_min3_f32", "v_fma_mix_f32", "v_pk_fma_f32", "v_rcp_f32", "v_cvt_f32_f64", "v_cvt_f64_f32", "v_cvt_f64_u32",
     "v_fma_f64", "v_add_f64", "v_mul_f64", "v_rcp_f64", "v_rsq_f64", "v_div_scale_f64", "v_div_fmas_f64", "v_div_fixup_f64", "v_cmp_lt_f64", "v_cmp_lt_f32",
     "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_add_u32", "v_addc_co_u32", "v_xor_b32", "v_lshrrev_b64", "v_lshlrev_b64", "v_lshrrev_b32", "v_alignbit_b32", "v_cndmask_b32",
-    "v_mov_b32", "v_bfe_u32", "v_and_or_b32", "v_mad_u32_u24", "ds_bpermute_b32", "v_readlane_b32", "s_add_u32 (scalar only)", "v_fma_f32 + s_add_u32 (1:1)", "ds_read_b32", "ds_write_b32"};
+    "v_mov_b32", "v_bfe_u32", "v_and_or_b32", "v_mad_u32_u24", "v_max_f32", "v_cmp_lt_f32 -> sgpr pair", "v_cvt_f32_f16", "v_add3_u32", "v_lshl_add_u64", "v_readfirstlane_b32", "ds_bpermute_b32", "v_readlane_b32", "s_add_u32 (scalar only)", "v_fma_f32 + s_add_u32 (1:1)", "ds_read_b32", "ds_write_b32"};
 // PMC class the instruction is counted in (SQ_INSTS_VALU_*), for bench.py's per-class pricing
 static const char *kClass[OP_COUNT] = {
     "FMA_F32", "ADD_F32", "MUL_F32", "other", "other", "FMA_F32?", "FMA_F32?", "TRANS_F32", "CVT", "CVT", "CVT",
     "FMA_F64", "ADD_F64", "MUL_F64", "TRANS_F64", "TRANS_F64", "other_f64", "FMA_F64?", "other_f64", "other_f64", "other",
     "INT32", "INT32", "INT64", "INT32", "INT32", "INT32", "INT64", "INT64", "INT32", "INT32", "other",
-    "other", "INT32", "INT32", "INT32", "lds", "other", "salu", "mix", "lds", "lds"};
+    "other", "INT32", "INT32", "INT32", "other", "other", "CVT", "INT32", "INT64", "other", "lds", "other", "salu", "mix", "lds", "lds"};
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
@@ -36,6 +36,7 @@ template <int OP> __global__ void __launch_bounds__(256) k(double *out, int iter
     unsigned u[8];
     unsigned long long q[8];
     unsigned s0 = seed, s1 = seed + 1, s2 = seed + 2, s3 = seed + 3;
+    unsigned long long smask = 0x5555555555555555ull * (seed | 1u), sm2 = 0;
     __shared__ unsigned lds[256 * 8];
     for (int i = 0; i < 8; ++i) {
         f[i] = 1.0f + 0.001f * (float)(lane + i + (int)seed);
@@ -84,7 +85,13 @@ template <int OP> __global__ void __launch_bounds__(256) k(double *out, int iter
     if (OP == OP_LSHL_B64) asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(q[i]) : "v"(sh));                                                     \
     if (OP == OP_LSHR_B32) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(u[i]) : "v"(sh));                                                     \
     if (OP == OP_ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %0, %1" : "+v"(u[i]) : "v"(sh));                                                \
-    if (OP == OP_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(um) : "vcc");                                         \
+    if (OP == OP_CNDMASK) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(u[i]) : "v"(um), "s"(smask));                                   \
+    if (OP == OP_MAX_F32) asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[i]) : "v"(fm));                                                          \
+    if (OP == OP_CMP_F32_SGPR) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(sm2) : "v"(f[i]), "v"(fm));                                    \
+    if (OP == OP_CVT_F32_F16) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(f[i]) : "v"(u[i]));                                                    \
+    if (OP == OP_ADD3_U32) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(um), "v"(sh));                                           \
+    if (OP == OP_LSHL_ADD_U64) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q[i]) : "v"(q[(i + 1) & 7]));                                 \
+    if (OP == OP_READFIRSTLANE) asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s0) : "v"(u[i]));                                              \
     if (OP == OP_MOV_B32) asm volatile("v_mov_b32 %0, %1" : "=v"(u[i]) : "v"(um));                                                              \
     if (OP == OP_BFE_U32) asm volatile("v_bfe_u32 %0, %0, %1, %1" : "+v"(u[i]) : "v"(sh));                                                      \
     if (OP == OP_AND_OR_B32) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(um), "v"(sh));                                       \
@@ -102,7 +109,7 @@ template <int OP> __global__ void __launch_bounds__(256) k(double *out, int iter
     }
     double acc = 0.0;
     for (int i = 0; i < 8; ++i) acc += (double)f[i] + d[i] + (double)u[i] + (double)q[i];
-    acc += (double)(s0 + s2 + s3);
+    acc += (double)(s0 + s2 + s3) + (double)(sm2 & 1ull);
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 

@@ -2,12 +2,14 @@
  * INTEGRATION.md) does, in plain C.  dlopen()s the library (so the HIP runtime it binds to is the system one, /opt/rocm),
  * builds a scene from flat arrays through rtmi_scene_create, renders through rtmi_render (core.clj:100-108 replaced), then
  * clones the scene onto a second context and renders again through the single-process multi-device entry
- * rtmi_render_multi.  Test infrastructure: built and run by tests/test_gpu_round2.py.
+ * rtmi_render_multi.  With RTMI_HOST_SMOKE_RCCL=1 in the environment a third frame goes through the in-library RCCL gather on a
+ * one-rank communicator (RTMI_MULTI_GATHER=rccl, one replica): this process opens /opt/rocm's librccl.so.1 by soname, as a JVM would.
+ * Test infrastructure: built and run by tests/test_gpu_round2.py and tests/test_gpu_round3.py.
  *
  *   host_smoke <librtmi.so> <scene.bin> <out.bin>
  *
  * scene.bin: int32 n_prims, n_mats, n_tex, cam_kind, nx, ny, ns, depth; uint64 seed; then the arrays of rtmi_scene_create
- * in argument order.  out.bin: twice { double linear[ny*nx*3]; uint8 rgb8[ny*nx*3]; uint64 counters[2] }. */
+ * in argument order.  out.bin: twice (three times with RTMI_HOST_SMOKE_RCCL) { double linear[ny*nx*3]; uint8 rgb8[ny*nx*3]; uint64 counters[2] }. */
 #include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -29,7 +31,7 @@ int main(int argc, char **argv) {
     void *h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
     LOAD(rtmi_last_error) LOAD(rtmi_backend_name) LOAD(rtmi_init) LOAD(rtmi_shutdown) LOAD(rtmi_scene_create) LOAD(rtmi_scene_clone)
-    LOAD(rtmi_scene_destroy) LOAD(rtmi_render) LOAD(rtmi_render_multi) LOAD(rtmi_device_info)
+    LOAD(rtmi_scene_destroy) LOAD(rtmi_render) LOAD(rtmi_render_multi) LOAD(rtmi_device_info) LOAD(rtmi_rccl_probe) LOAD(rtmi_last_gather_path)
     FILE *f = fopen(argv[2], "rb");
     if (!f) { perror(argv[2]); return 4; }
     int32_t *hd = (int32_t *)rd(f, 8 * sizeof(int32_t));
@@ -70,6 +72,21 @@ int main(int argc, char **argv) {
     cnt[0] = cnt[1] = 0;
     CHECK(p_rtmi_render_multi(2, both, nx, ny, ns, depth, *seed, RTMI_F64, lin, q, cnt));
     fwrite(lin, sizeof(double), npx * 3, o); fwrite(q, 1, npx * 3, o); fwrite(cnt, sizeof(uint64_t), 2, o);
+    if (getenv("RTMI_HOST_SMOKE_RCCL")) { /* the RCCL branch on a one-GPU host: a one-rank communicator */
+        CHECK(p_rtmi_rccl_probe(NULL));
+        printf("rccl probe ok\n");
+        if (p_rtmi_rccl_probe("librccl_does_not_exist.so.9") == RTMI_OK) { fprintf(stderr, "probe of a missing library succeeded\n"); return 5; }
+        printf("missing library: %s\n", p_rtmi_last_error());
+        setenv("RTMI_MULTI_GATHER", "rccl", 1);
+        rtmi_scene *one[1] = {scene};
+        cnt[0] = cnt[1] = 0;
+        CHECK(p_rtmi_render_multi(1, one, nx, ny, ns, depth, *seed, RTMI_F64, lin, q, cnt));
+        int32_t path = -1;
+        CHECK(p_rtmi_last_gather_path(ctx, &path));
+        printf("gather path of the one-rank frame: %d\n", (int)path);
+        fwrite(lin, sizeof(double), npx * 3, o); fwrite(q, 1, npx * 3, o); fwrite(cnt, sizeof(uint64_t), 2, o);
+        unsetenv("RTMI_MULTI_GATHER");
+    }
     fclose(o);
     CHECK(p_rtmi_scene_destroy(clone));
     CHECK(p_rtmi_scene_destroy(scene));

@@ -1,0 +1,287 @@
+"""Static conformance of the Clojure / JNA host (clj/src/raytrace_clj/gpu.clj, written without a JVM) and of INTEGRATION.md's Clojure
+snippets against the C-ABI they bind (include/rtmi.h): every (call-int "rtmi_..." ...) form must name a declared symbol with the declared
+number of arguments; every scalar argument must be coerced at the call site ((int ...) for int / int32_t / uint32_t, (long ...) for
+int64_t / uint64_t, (double ...) for double: JNA marshals by the boxed Java type, so an un-coerced Long in an int32_t slot only works by
+accident of the calling convention); every array argument must be a primitive array of the header's element type; handles are Pointers,
+handle outputs PointerByReference, handle lists Pointer arrays.  No JVM is needed (or available): this is a reader over the source text."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rtmi.h")
+GPU_CLJ = os.path.join(ROOT, "clj", "src", "raytrace_clj", "gpu.clj")
+INTEGRATION = os.path.join(ROOT, "INTEGRATION.md")
+
+
+# ---- the header: name -> list of parameter categories ------------------------------------------------------------------------------------
+def _category(ctype):
+    if re.search(r"\*\s*const\s*\*", ctype):  # T *const *: a read-only array of handles
+        return "handle-array"
+    t = re.sub(r"\s+", " ", ctype.replace("const ", " ").strip())
+    t = t.replace(" *", "*").replace("* ", "*")
+    table = {"int": "i32", "int32_t": "i32", "uint32_t": "i32", "int64_t": "i64", "uint64_t": "i64", "double": "f64", "char*": "string",
+             "rtmi_ctx*": "handle", "rtmi_scene*": "handle", "rtmi_ctx**": "handle-out", "rtmi_scene**": "handle-out", "rtmi_scene**const": "handle-array",
+             "rtmi_scene*const*": "handle-array", "int32_t*": "int[]", "double*": "double[]", "uint8_t*": "byte[]", "uint64_t*": "long[]", "int64_t*": "long[]",
+             "void*": "device-pointer", "char*out": "string"}
+    assert t in table, "unknown C type in rtmi.h: %r" % ctype
+    return table[t]
+
+
+def header_prototypes():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b([a-z_0-9]+(?:\s+[a-z_0-9]+)*\s*\**)\s*\b(rtmi_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        name, args = m.group(2), m.group(3).strip()
+        cats = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                mm = re.match(r"(.*?)([A-Za-z_][A-Za-z_0-9]*)$", a)  # type, then the parameter name
+                cats.append(_category(mm.group(1)))
+        protos[name] = cats
+    return protos
+
+
+# ---- a reader for Clojure source: nested lists of tokens ---------------------------------------------------------------------------------
+def read_forms(src):
+    pos, n = 0, len(src)
+    close = {"(": ")", "[": "]", "{": "}"}
+
+    def skip():
+        nonlocal pos
+        while pos < n:
+            c = src[pos]
+            if c in " \t\r\n,":
+                pos += 1
+            elif c == ";":
+                while pos < n and src[pos] != "\n":
+                    pos += 1
+            else:
+                break
+
+    def read():
+        nonlocal pos
+        skip()
+        if pos >= n:
+            return None
+        c = src[pos]
+        if c in close:
+            pos += 1
+            items = [c]
+            while True:
+                skip()
+                assert pos < n, "unbalanced %s" % c
+                if src[pos] == close[c]:
+                    pos += 1
+                    return items
+                items.append(read())
+        if c == '"':
+            j = pos + 1
+            while src[j] != '"':
+                j += 2 if src[j] == "\\" else 1
+            tok = src[pos:j + 1]
+            pos = j + 1
+            return tok
+        if c in "'`@~":  # reader macros that wrap the next form
+            pos += 1
+            return [c, read()]
+        if c == "^":     # metadata / type hint: drop it, return the hinted form
+            pos += 1
+            read()
+            return read()
+        if c == "#":     # #( ... ) anonymous fn, #{ } set, #' var
+            pos += 1
+            if src[pos] == "'":
+                pos += 1
+            return ["#", read()]
+        if c == "\\":    # character literal
+            j = pos + 2
+            while j < n and re.match(r"[A-Za-z0-9]", src[j]):
+                j += 1
+            tok = src[pos:j]
+            pos = j
+            return tok
+        j = pos
+        while j < n and src[j] not in " \t\r\n,()[]{}\";":
+            j += 1
+        tok = src[pos:j]
+        pos = j
+        return tok
+
+    forms = []
+    while True:
+        f = read()
+        if f is None:
+            return forms
+        forms.append(f)
+
+
+def is_list(f, head=None):
+    return isinstance(f, list) and len(f) > 1 and f[0] == "(" and (head is None or f[1] == head)
+
+
+def walk(f):
+    yield f
+    if isinstance(f, list):
+        for x in f[1:]:
+            yield from walk(x)
+
+
+def let_bindings(top):
+    """symbol -> value form for every let / binding vector inside one top-level form (later bindings shadow earlier ones: fine for this file)"""
+    env = {}
+    for f in walk(top):
+        if isinstance(f, list) and f[0] == "(" and len(f) > 2 and f[1] in ("let", "when-let", "if-let", "loop") and isinstance(f[2], list) and f[2][0] == "[":
+            b = f[2][1:]
+            for k in range(0, len(b) - 1, 2):
+                if isinstance(b[k], str):
+                    env[b[k]] = b[k + 1]
+    return env
+
+
+def map_values(form):
+    """{:key value ...} literal -> dict"""
+    out = {}
+    items = form[1:]
+    for k in range(0, len(items) - 1, 2):
+        if isinstance(items[k], str) and items[k].startswith(":"):
+            out[items[k]] = items[k + 1]
+    return out
+
+
+ARRAY_CTORS = {"int-array": "int[]", "double-array": "double[]", "byte-array": "byte[]", "long-array": "long[]"}
+
+
+def classify(arg, env, flat_map, params):
+    """category of one call-int argument form"""
+    if isinstance(arg, str):
+        if arg.startswith('"'):
+            return "string"
+        if re.match(r"^-?[0-9]", arg):
+            return "bare-number"
+        if arg in env:
+            return classify(env[arg], env, flat_map, params)
+        if arg in params:
+            return "param"
+        return "unknown-symbol:" + arg
+    if is_list(arg):
+        head = arg[1]
+        if head in ("int", "long", "double"):
+            return {"int": "i32", "long": "i64", "double": "f64"}[head]
+        if head in ARRAY_CTORS:
+            return ARRAY_CTORS[head]
+        if head == "PointerByReference.":
+            return "handle-out"
+        if head in (".getValue", "create-scene!"):
+            return "handle"
+        if head == "into-array":
+            return "handle-array" if arg[2] in ("com.sun.jna.Pointer", "Pointer") else "array-of-" + str(arg[2])
+        if head in ("first", "nth", "second"):  # an element of a vector of handles
+            inner = classify(arg[2], env, flat_map, params)
+            return "handle" if inner in ("handles", "param") else "element-of-" + inner
+        if head == "mapv":  # (mapv (fn [...] ... (.getValue x)) coll): a vector of handles
+            return "handles" if any(is_list(x, ".getValue") for x in walk(arg)) else "vector"
+        if isinstance(head, str) and head.startswith(":") and len(arg) == 3 and isinstance(arg[2], str):  # (:key f): a field of flatten-scene's result
+            v = flat_map.get(head)
+            assert v is not None, "flatten-scene returns no %s" % head
+            c = classify(v, {}, flat_map, set())
+            return {"i32": "boxed-int"}.get(c, c)
+    return "unclassified:" + repr(arg)[:60]
+
+
+COMPATIBLE = {
+    "i32": {"i32"}, "i64": {"i64"}, "f64": {"f64"}, "string": {"string"},
+    "handle": {"handle", "param"},  # a function / doseq parameter that can only be a handle where the header wants one
+    "handle-out": {"handle-out"}, "handle-array": {"handle-array"},
+    "int[]": {"int[]"}, "double[]": {"double[]"}, "byte[]": {"byte[]"}, "long[]": {"long[]"},
+}
+
+
+def check_calls(forms, protos, flat_map, strict_arrays, where):
+    n_calls = 0
+    for top in forms:
+        env = let_bindings(top)
+        params = set()
+        for f in walk(top):  # parameters of defn / fn / doseq / for in this top-level form
+            if isinstance(f, list) and f[0] == "(" and len(f) > 2 and f[1] in ("fn", "defn", "defn-", "doseq", "for"):
+                for v in f[2:5]:
+                    if isinstance(v, list) and v[0] == "[":
+                        params.update(x for x in v[1:] if isinstance(x, str))
+        for f in walk(top):
+            if not is_list(f, "call-int") or not (isinstance(f[2], str) and f[2].startswith('"rtmi_')):
+                continue
+            name, args = f[2].strip('"'), f[3:]
+            n_calls += 1
+            assert name in protos, "%s: %s is not declared in include/rtmi.h" % (where, name)
+            want = protos[name]
+            assert len(args) == len(want), "%s: %s takes %d arguments, the call passes %d" % (where, name, len(want), len(args))
+            for k, (a, w) in enumerate(zip(args, want)):
+                got = classify(a, env, flat_map, params)
+                if not strict_arrays and w not in ("i32", "i64", "f64") and (got.startswith("unknown-symbol") or got == "param"):
+                    continue  # documentation snippet: arrays / handles are named, not constructed
+                assert got in COMPATIBLE[w], "%s: %s argument %d: header wants %s, the call passes %s (%r)" % (where, name, k + 1, w, got, a)
+    return n_calls
+
+
+def test_header_prototypes_are_all_parsed():
+    import raytrace_clj_amd._ffi as ffi
+    protos = header_prototypes()
+    assert sorted(protos) == sorted(ffi.SYMBOLS), "the reader must see every prototype of include/rtmi.h"
+    assert protos["rtmi_render"] == ["handle", "i32", "i32", "i32", "i32", "i64", "i32", "i32", "i32", "i32", "i32", "double[]", "byte[]", "long[]"]
+    assert protos["rtmi_scene_create_ex"][-6:] == ["int[]", "int[]", "i32", "int[]", "double[]", "handle-out"] and len(protos["rtmi_scene_create_ex"]) == 21
+    assert protos["rtmi_render_multi"][:2] == ["i32", "handle-array"]
+
+
+def test_gpu_clj_calls_conform_to_the_header():
+    protos = header_prototypes()
+    forms = read_forms(open(GPU_CLJ).read())
+    flat = [f for f in forms if is_list(f, "defn") and f[2] == "flatten-scene"]
+    assert len(flat) == 1
+    maps = [f for f in walk(flat[0]) if isinstance(f, list) and f[0] == "{" and any(x == ":prim-kind" for x in f[1:])]
+    assert len(maps) == 1, "flatten-scene's result map"
+    flat_map = map_values(maps[0])
+    n = check_calls(forms, protos, flat_map, True, "gpu.clj")
+    assert n >= 10
+    called = {f[2].strip('"') for top in forms for f in walk(top) if is_list(f, "call-int")}
+    # the one-GPU path and the multi-GPU path must both create the scene WITH its Perlin tables, ImageMap pixels and media calls
+    for need in ("rtmi_init", "rtmi_scene_create_ex", "rtmi_scene_set_perlin", "rtmi_scene_set_images", "rtmi_scene_set_media_calls", "rtmi_render",
+                 "rtmi_scene_clone", "rtmi_render_multi", "rtmi_scene_destroy", "rtmi_shutdown"):
+        assert need in called, need
+    by_name = {f[2]: f for f in forms if isinstance(f, list) and len(f) > 2 and f[1] in ("defn", "defn-")}
+    for entry in ("render", "render-multi"):
+        uses = {x[1] for x in walk(by_name[entry]) if is_list(x)}
+        assert "create-scene!" in uses, "%s must build its scene through create-scene! (images, Perlin tables, media calls)" % entry
+    helper = {f[2].strip('"') for f in walk(by_name["create-scene!"]) if is_list(f, "call-int")}
+    assert helper == {"rtmi_scene_create_ex", "rtmi_scene_set_perlin", "rtmi_scene_set_images", "rtmi_scene_set_media_calls"}
+
+
+def test_integration_md_snippets_conform_to_the_header():
+    protos = header_prototypes()
+    text = open(INTEGRATION).read()
+    blocks = re.findall(r"```clojure\n(.*?)```", text, flags=re.S)
+    assert len(blocks) >= 3
+    n = 0
+    for b in blocks:
+        forms = read_forms(b.replace("…", " "))
+        n += check_calls(forms, protos, {}, False, "INTEGRATION.md")
+    assert n >= 3
+
+
+def test_reader_rejects_what_it_should():
+    """the checker itself: an un-coerced scalar, a wrong array type, a wrong arity and an undeclared symbol are all caught"""
+    import pytest
+    protos = header_prototypes()
+    flat_map = {":cam-kind": ["(", "int", ["(", ":kind", "cam"]], ":cam": ["(", "double-array", "x"], ":prim-kind": ["(", "int-array", "x"]}
+    bad = [
+        '(defn f [scn] (let [lin (double-array 3) rgb (byte-array 3) cnt (long-array 2)] (call-int "rtmi_render" scn (int 1) (int 1) (int 1) (int 1) 7 (int 0) (int 0) (int 0) (int 1) (int 1) lin rgb cnt)))',
+        '(defn f [scn] (let [lin (double-array 3) rgb (byte-array 3) cnt (int-array 2)] (call-int "rtmi_render" scn (int 1) (int 1) (int 1) (int 1) (long 7) (int 0) (int 0) (int 0) (int 1) (int 1) lin rgb cnt)))',
+        '(defn f [scn] (call-int "rtmi_scene_destroy" scn (int 0)))',
+        '(defn f [scn] (call-int "rtmi_scene_frobnicate" scn))',
+        '(defn g [ctx f] (let [scn (PointerByReference.)] (call-int "rtmi_scene_create" ctx (int 1) (:prim-kind f) (:cam f) (:prim-kind f) (int 1) (:prim-kind f) (:prim-kind f) (:cam f) (int 1) (:prim-kind f) (:cam f) (:prim-kind f) (:cam-kind f) (:cam f) scn)))',
+    ]
+    for src in bad:
+        with pytest.raises(AssertionError):
+            check_calls(read_forms(src), protos, flat_map, True, "synthetic")
+    good = '(defn g [ctx f] (let [scn (PointerByReference.)] (call-int "rtmi_scene_create" ctx (int 1) (:prim-kind f) (:cam f) (:prim-kind f) (int 1) (:prim-kind f) (:prim-kind f) (:cam f) (int 1) (:prim-kind f) (:cam f) (:prim-kind f) (int (:cam-kind f)) (:cam f) scn)))'
+    assert check_calls(read_forms(good), protos, flat_map, True, "synthetic") == 1

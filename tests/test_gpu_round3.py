@@ -287,3 +287,33 @@ def test_config_c5_many_passes(oracle):
     exp, eq, ecnt = oracle.render(flat, nx, ny, ns, 50, core.RENDER_SEED, region=region, nthreads=64)
     assert rms(lin, exp) < 1e-13 and np.array_equal(cr, ecnt) and np.array_equal(lin, base[700:704, 1000:1008])
     ds.close(); ctx.close()
+
+
+# ---- metrics.clj:10 aabb.intersection.total for the mixed-kind (f3 / f4) kernels ------------------------------------------------------------
+def test_traversal_counters_of_the_mixed_kind_kernels():
+    """rtmi_last_traversal_counters for scenes the EXT instantiations render (rectangles, instances, media, procedural textures): the
+    counting instantiation renders the same image, the counts are deterministic, independent of the time-slicing threshold and of the sample
+    pass split, and of a plausible size (a few to a few dozen node visits per segment)"""
+    for name, scene, nx, ny, ns in (("cornell", r.scene.make_cornell_box(64, 64), 64, 64, 8), ("final", r.scene.make_final(96, 96), 96, 96, 4)):
+        flat = fl.flatten(scene)
+        ref = None
+        for lanes in (8, 0, 33):
+            ctx = core.Context(0)
+            ctx.set_option("suspend_lanes", lanes)
+            ds = core.DeviceScene(flat, ctx=ctx)
+            base = ds.render(nx, ny, ns)
+            ctx.set_option("count_traversal", 1)
+            counted = ds.render(nx, ny, ns)
+            trav = ctx.last_traversal_counters()
+            ctx.set_option("workspace_bytes", 1 << 20)
+            ds.render(nx, ny, ns)
+            assert ctx.last_traversal_counters() == trav, (name, "pass split")
+            ds.close(); ctx.close()
+            for x, y in zip(base, counted):
+                assert np.array_equal(x, y), name
+            rays = int(base[2][0])
+            assert trav[0] % 2 == 0 and 2 * rays <= trav[0] < 400 * rays and rays <= trav[1] < 100 * rays, (name, trav, rays)
+            if ref is None:
+                ref = (base, trav)
+            else:
+                assert np.array_equal(base[0], ref[0][0]) and trav == ref[1], (name, lanes)

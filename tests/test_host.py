@@ -188,6 +188,18 @@ def test_library_exports_every_declared_symbol():
     assert L.rtmi_local_tiles(200, 100, 0, 1) == 25 * 13
 
 
+def test_rccl_probe_reports_a_missing_library_without_crashing():
+    """rtmi_rccl_probe: the open / resolve step of the in-library RCCL gather, callable without a device.  A missing library must come back
+    as RTMI_E_DEVICE with the loader's message (round 2 built that message from a SECOND dlerror() call, which returns NULL)."""
+    L = _ffi.lib()
+    assert L.rtmi_rccl_probe(b"librccl_does_not_exist.so.9") == -2
+    msg = L.rtmi_last_error().decode()
+    assert "dlopen(librccl_does_not_exist.so.9)" in msg and "cannot open shared object file" in msg
+    assert L.rtmi_rccl_probe(b"libm.so.6") == -2 and "lacks ncclCommInitAll" in L.rtmi_last_error().decode()  # opens, but is not an RCCL
+    if os.path.exists("/opt/rocm/lib/librccl.so.1"):
+        assert L.rtmi_rccl_probe(None) == 0, L.rtmi_last_error()
+
+
 def test_no_device_is_a_loud_error():
     import torch
     if torch.cuda.is_available():
