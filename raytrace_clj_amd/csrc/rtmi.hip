@@ -674,7 +674,7 @@ struct rtmi_ctx {
     double last_reduce_ms = 0.0;      // of the window rtmi_last_trace_ms closed last
     int last_reduce_launches = 0;
     int count_traversal = 0;      // option "count_traversal": run the COUNT instantiation of the BVH kernels
-    int suspend_lanes = 8;        // option "suspend_lanes": threshold of the time-sliced BVH traversal (0 = plain while-while loop)
+    int suspend_lanes = 12;       // option "suspend_lanes": threshold of the time-sliced BVH traversal (0 = plain while-while loop); 8 .. 16 within 0.5 %
     hipStream_t last_stream = nullptr; // stream of the most recent render (rtmi_last_traversal_counters synchronises on it)
     long long tile_valid_pixels = 0;
     // timing
@@ -1120,7 +1120,8 @@ bool prim_world_box(int kind, const double *g, const int32_t *xf_kind, const dou
 }
 
 // fills d.bvh_* ; returns the node array to upload.  wbox[i] / bounded[i]: prim_world_box of every primitive.
-std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, const std::vector<BvhBox> &wbox, const std::vector<char> &bounded, const double *cam) {
+std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, const std::vector<BvhBox> &wbox, const std::vector<char> &bounded, const double *cam,
+                             bool want_grid, std::vector<int> &grid_cells) {
     BvhBuilder B;
     std::vector<BvhItem> all;
     double obound = 0.0;
@@ -1171,6 +1172,77 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
             B.nodes.clear();
         }
     }
+    // ---- entry grid: a BVH per x-z cell over the primitives whose boxes overlap the cell (DevScene::grid_*) -------------------------------------
+    d.grid_n = 0; d.grid_tall = RTMI_BVH_EMPTY; d.grid_kmax = 4;
+    grid_cells.clear();
+    const char *grid_env = std::getenv("RTMI_GRID"); // "0": off; "n": n x n cells (experiments)
+    if (want_grid && d.bvh_root >= 0 && !(grid_env && grid_env[0] == '0') && B.items.size() >= 256) {
+        const size_t n_items = B.items.size();
+        std::vector<BvhItem> world(B.items.begin(), B.items.begin() + (long)n_items); // (build() has reordered them; any order will do)
+        // the layer: every primitive except the few much taller than the typical one (the cover scene's three big spheres among 10 000 small ones)
+        std::vector<double> hts(n_items);
+        for (size_t i = 0; i < n_items; ++i) hts[i] = world[i].b.hi[1] - world[i].b.lo[1];
+        std::vector<double> sorted_h(hts);
+        std::nth_element(sorted_h.begin(), sorted_h.begin() + (long)(n_items / 2), sorted_h.end());
+        const double tall_h = 3.0 * sorted_h[n_items / 2] + 1e-300;
+        std::vector<BvhItem> layer, tall;
+        for (size_t i = 0; i < n_items; ++i) (hts[i] > tall_h ? tall : layer).push_back(world[i]);
+        BvhBox lb = box_empty();
+        for (const BvhItem &it : layer) box_grow(lb, it.b);
+        const double ex = lb.hi[0] - lb.lo[0], ez = lb.hi[2] - lb.lo[2], ey = lb.hi[1] - lb.lo[1];
+        int G = (int)std::lround(std::sqrt((double)layer.size() / 10.0)); // ~10 primitives per cell (C3: 32 x 32 cells; measured 16 .. 48: 84.1 / 82.3 / 83.3 ms)
+        if (grid_env && std::atoi(grid_env) > 1) G = std::atoi(grid_env);
+        G = std::max(2, std::min(G, 96));
+        // worth it for a flat, wide layer of many primitives with few tall outliers
+        if (layer.size() >= 256 && tall.size() * 20 <= n_items && ex > 0 && ez > 0 && ey < 0.25 * std::min(ex, ez)) {
+            const double eps = 4.0 * B.delta; // cells claim the primitives whose (already inflated) boxes come this close; the device grows a ray's cell rectangle by its own position error
+            const double csx = ex / G, csz = ez / G;
+            std::vector<std::vector<int>> cell_items((size_t)G * G);
+            for (size_t i = 0; i < layer.size(); ++i) {
+                const BvhBox &b = layer[i].b;
+                const int i0 = std::max(0, std::min(G - 1, (int)std::floor((b.lo[0] - 2 * eps - lb.lo[0]) / csx))), i1 = std::max(0, std::min(G - 1, (int)std::floor((b.hi[0] + 2 * eps - lb.lo[0]) / csx)));
+                const int j0 = std::max(0, std::min(G - 1, (int)std::floor((b.lo[2] - 2 * eps - lb.lo[2]) / csz))), j1 = std::max(0, std::min(G - 1, (int)std::floor((b.hi[2] + 2 * eps - lb.lo[2]) / csz)));
+                for (int j = j0; j <= j1; ++j) for (int ii = i0; ii <= i1; ++ii) cell_items[(size_t)j * G + ii].push_back((int)i);
+            }
+            const int depth0 = 6; // stack entries a grid start may already hold: up to grid_kmax cells + the tall tree (+ margin)
+            auto subtree = [&](const std::vector<BvhItem> &its) -> int { // child code of a tree over `its`, appended to B.nodes
+                if (its.empty()) return RTMI_BVH_EMPTY;
+                const int b0 = (int)B.items.size();
+                B.items.insert(B.items.end(), its.begin(), its.end());
+                if (its.size() == 1) { // a lone primitive: a node whose right child is an empty box (a bare leaf code would skip the box test)
+                    const int node = (int)(B.nodes.size() / 16);
+                    B.nodes.resize(B.nodes.size() + 16, 0.0f);
+                    B.put_box(node, 0, its[0].b);
+                    B.put_empty_box(node, 1);
+                    const int l = B.leaf_code(its[0].idx);
+                    std::memcpy(&B.nodes[(size_t)node * 16 + 12], &l, 4); std::memcpy(&B.nodes[(size_t)node * 16 + 13], &l, 4);
+                    return node * 64;
+                }
+                return B.build(b0, b0 + (int)its.size(), depth0);
+            };
+            grid_cells.assign((size_t)G * G, RTMI_BVH_EMPTY);
+            std::vector<BvhItem> tmp;
+            for (size_t cidx = 0; cidx < cell_items.size(); ++cidx) {
+                tmp.clear();
+                for (int k : cell_items[cidx]) tmp.push_back(layer[(size_t)k]);
+                grid_cells[cidx] = subtree(tmp);
+            }
+            d.grid_tall = subtree(tall);
+            if (B.max_depth >= RTMI_BVH_STACK - 1 || B.nodes.size() / 16 >= (1u << 25)) { // too deep for the stack: no grid (the whole tree above stays valid)
+                grid_cells.clear(); d.grid_tall = RTMI_BVH_EMPTY;
+            } else {
+                d.grid_n = G;
+                if (const char *e = std::getenv("RTMI_GRID_KMAX")) d.grid_kmax = std::max(1, std::min(4, std::atoi(e)));
+                d.grid_lo_x = (float)lb.lo[0]; d.grid_lo_z = (float)lb.lo[2];
+                d.grid_inv_x = (float)(1.0 / csx); d.grid_inv_z = (float)(1.0 / csz);
+                for (int k = 0; k < 3; ++k) { d.grid_box[k] = f_down(lb.lo[k] - B.delta - eps); d.grid_box[3 + k] = f_up(lb.hi[k] + B.delta + eps); }
+                d.grid_eps = 0.0f;
+                BvhBox tb = box_empty();
+                for (const BvhItem &it : tall) box_grow(tb, it.b);
+                for (int k = 0; k < 3; ++k) { d.grid_tall_box[k] = tall.empty() ? 0.0f : f_down(tb.lo[k] - B.delta - eps); d.grid_tall_box[3 + k] = tall.empty() ? 0.0f : f_up(tb.hi[k] + B.delta + eps); }
+            }
+        }
+    }
     d.bvh_node16 = 0;
     if (d.bvh_root != RTMI_BVH_EMPTY) { // 32-byte records (Node16) when rounding the planes to half costs little: 12 halves + 2 child codes
         auto half_bits = [](float x, bool up) {
@@ -1213,6 +1285,8 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
         if (use16) {
             d.bvh_node16 = 1;
             d.bvh_root = d.bvh_root >= 0 ? d.bvh_root / 2 : d.bvh_root;
+            for (int &c : grid_cells) if (c >= 0) c /= 2;
+            if (d.grid_tall >= 0) d.grid_tall /= 2;
             return out;
         }
     }
@@ -1548,9 +1622,11 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     d.n_media = n_media;
     for (int k = 0; k < n_media; ++k) d.media_idx[k] = media[k];
     s->host_kind = pk;
-    const std::vector<float> bvh_nodes = build_bvh(d, n_world, pk.data(), wbox, bounded, cam);
+    std::vector<int> grid_cells;
+    const std::vector<float> bvh_nodes = build_bvh(d, n_world, pk.data(), wbox, bounded, cam, !has_ext, grid_cells);
     s->bvh_node_count = (int)(bvh_nodes.size() / (d.bvh_node16 ? 8 : 16));
     if (!rc) rc = upload(s, bvh_nodes, &d.bvh_nodes);
+    if (!rc) rc = upload(s, grid_cells, &d.grid_cells);
     std::vector<int> moving_all;
     for (int i = 0; i < n_world; ++i) if (pk[(size_t)i] == RTMI_PRIM_MOVING) moving_all.push_back(i);
     d.n_moving_all = (int)moving_all.size();

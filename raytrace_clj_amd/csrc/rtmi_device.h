@@ -39,6 +39,18 @@ struct DevScene {
     float bvh_cbound;        // largest |coordinate| of the boxes in the tree (the big primitives are outside it)
     int n_moving_all;        // all MovingSphere world primitives (tested exhaustively for rays outside the shutter interval)
     const int *moving_all;
+    // Entry grid (sphere-only scenes whose primitives form a layer over the x-z plane, e.g. the cover scene): the layer is cut into
+    // grid_n x grid_n cells, every cell owns a BVH over the primitives whose boxes overlap it (a primitive on a border is in several), the
+    // few primitives much taller than the rest form one more small tree.  A ray whose clipped segment stays within grid_kmax cells starts
+    // at those cells' roots instead of descending from the root of the whole tree (half of a traversal's node visits only locate the ray).
+    int grid_n;              // 0: no grid
+    int grid_kmax;           // rays touching more cells than this take the whole tree
+    int grid_tall;           // root code of the tall primitives' tree (RTMI_BVH_EMPTY: none)
+    float grid_lo_x, grid_lo_z, grid_inv_x, grid_inv_z; // cell index = floor((p - lo) * inv)
+    float grid_box[6];       // lo.xyz hi.xyz of the layer primitives' boxes (rounded outward like every node box): a ray's t range inside it
+    float grid_tall_box[6];  // the same for the tall primitives: their tree is entered only by rays that meet this box
+    float grid_eps;          // the cell rectangle of a segment is grown by this much (float position error, far below a cell)
+    const int *grid_cells;   // [grid_n * grid_n] root codes (row = z cell, column = x cell)
     // section 8(f3): rectangles / triangles and FlipNormals / Translate / RotateY instances (hitable.clj:269-511, 548-581)
     int has_ext;             // any primitive kind > 2, any instance wrapper, any flip
     const int *ext_info;     // [n_all][4]: kind, FlipNormals parity, first xform, xform count (outermost first)
@@ -116,6 +128,9 @@ __device__ inline void ph_stamp(int k, unsigned lane_trips = 0, unsigned trips =
 }
 #define RTMI_PH(k) ph_stamp(k);
 #define RTMI_PH_LANES(k, lt, tr) ph_stamp(k, lt, tr);
+#elif defined(RTMI_MARKERS) // static analysis build (scripts/isa_phases.py): an assembler comment at every phase boundary, no code
+#define RTMI_PH(k) asm volatile("; PHASE_END " #k);
+#define RTMI_PH_LANES(k, lt, tr) asm volatile("; PHASE_END " #k);
 #else
 #define RTMI_PH(k)
 #define RTMI_PH_LANES(k, lt, tr)
@@ -475,7 +490,7 @@ template <> __device__ inline int sin_sign<double>(double x) {
     const double k = ::rint(x * 0.3183098861837907);
     double r = ::fma(-k, 3.141592653589793, x);
     r = ::fma(-k, 1.2246467991473532e-16, r);
-    const bool odd = ((long long)k) & 1;
+    const bool odd = ((int)k) & 1; // |k| <= 1e5 / pi: one v_cvt_i32_f64 (a 64-bit integer conversion is five instructions)
     return (odd != (r < 0.0)) ? -1 : 1;
 }
 
@@ -970,7 +985,13 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, const BvhRay &r, BvhCursor 
         RTMI_PH(PH_BVH_POST) // loop control between the phases
         unsigned st_trips = 0, st_lane_trips = 0;
 #endif
+#ifdef RTMI_MARKERS
+        RTMI_PH(PH_BVH_POST)
+#endif
         while (descend) { // inner node: both child boxes come with it (one record)
+#ifdef RTMI_MARKERS
+            asm volatile("; PHASE_BEGIN PH_DESCENT");
+#endif
 #ifdef RTMI_STAMPS
             st_trips += 1; st_lane_trips += (unsigned)__popcll(__ballot(1));
 #endif
@@ -1028,6 +1049,9 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, const BvhRay &r, BvhCursor 
 #ifdef RTMI_STAMPS
             if (__ballot(descend) == 0) { RTMI_PH_LANES(PH_DESCENT, st_lane_trips, st_trips) } // the wave's last trip: these lanes were in every trip
 #endif
+#ifdef RTMI_MARKERS
+            RTMI_PH(PH_DESCENT)
+#endif
         }
         if (node < 0 && node != RTMI_BVH_EMPTY) { // leaf: one primitive, exact FP64 test
 #ifdef RTMI_HIST
@@ -1041,6 +1065,66 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, const BvhRay &r, BvhCursor 
         }
         if (SLICE && __popcll(__ballot(node != RTMI_BVH_EMPTY)) < min_lanes) break; // wave-uniform
     }
+    cur.node = node; cur.tos = tos; cur.top = top;
+}
+
+// Entry grid (DevScene::grid_*): where does this ray's traversal START?  Half of the node visits of a ray from the root only locate it -- the
+// boxes of the top ten levels nearly all contain a ray that starts inside the scene.  The layer of primitives is cut into x-z cells with a
+// BVH each; the ray's parameter range inside the layer's box (the slab test of one more box, with the constants of make_bvh_ray, cut at the
+// closest hit so far -- the ground, usually) gives a segment, the segment's end points a rectangle of cells.  If that rectangle is at most
+// 2 x 2 cells and grid_kmax cells, the traversal starts with those cells' roots (nearest first) and the tall primitives' tree on the
+// stack; otherwise at the root of the whole tree.  Every primitive the ray can hit within its range overlaps one of those cells or is tall:
+// the end points carry a float error below 2^-21 (|o| + cbound) and the rectangle is grown by 2^-16 of that; cells claim primitives by
+// their inflated boxes.  A primitive two cells share is tested twice at worst (same t, same index: the any-order rule keeps one).
+// e_rel: rectangle growth relative to |o| + cbound -- RTMI_F32's float sphere test calls a hit up to 3.1e-3 (|o| + cbound) outside the sphere
+// (make_bvh_ray), so its rectangle grows by that much more.
+__device__ inline void bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, float oy, float oz, float dx, float dy, float dz, float best_hi, float e_rel, BvhCursor &cur) {
+    const int G = sc.grid_n;
+    const float bx0 = sc.grid_box[0], by0 = sc.grid_box[1], bz0 = sc.grid_box[2], bx1 = sc.grid_box[3], by1 = sc.grid_box[4], bz1 = sc.grid_box[5];
+    // entry plane of an axis = its lo plane for a ray travelling up that axis (shx == 0), else its hi plane; constants as in the node test
+    const float tn = fmaxf(fmaxf(fmaf(r.shx ? bx1 : bx0, r.ixy.x, r.cex), fmaf(r.shy ? by1 : by0, r.ixy.y, r.cey)), fmaxf(fmaf(r.shz ? bz1 : bz0, r.izz.x, r.cez), r.tmin_lo));
+    const float tf = fminf(fminf(fmaf(r.shx ? bx0 : bx1, r.ixy.x, r.cxx), fmaf(r.shy ? by0 : by1, r.ixy.y, r.cxy)), fminf(fmaf(r.shz ? bz0 : bz1, r.izz.x, r.cxz), best_hi));
+    int tall = sc.grid_tall;
+    if (tall != RTMI_BVH_EMPTY) { // (wave-uniform) the tall primitives' tree: only if the ray meets their box within its range
+        const float ux0 = sc.grid_tall_box[0], uy0 = sc.grid_tall_box[1], uz0 = sc.grid_tall_box[2], ux1 = sc.grid_tall_box[3], uy1 = sc.grid_tall_box[4], uz1 = sc.grid_tall_box[5];
+        const float un = fmaxf(fmaxf(fmaf(r.shx ? ux1 : ux0, r.ixy.x, r.cex), fmaf(r.shy ? uy1 : uy0, r.ixy.y, r.cey)), fmaxf(fmaf(r.shz ? uz1 : uz0, r.izz.x, r.cez), r.tmin_lo));
+        const float uf = fminf(fminf(fmaf(r.shx ? ux0 : ux1, r.ixy.x, r.cxx), fmaf(r.shy ? uy0 : uy1, r.ixy.y, r.cxy)), fminf(fmaf(r.shz ? uz0 : uz1, r.izz.x, r.cxz), best_hi));
+        tall = un > uf ? RTMI_BVH_EMPTY : tall; // (a NaN keeps the tree)
+    }
+    int c0 = RTMI_BVH_EMPTY, c1 = RTMI_BVH_EMPTY, c2 = RTMI_BVH_EMPTY, c3 = RTMI_BVH_EMPTY, near = RTMI_BVH_EMPTY;
+    if (tn <= tf) {
+        const float omax = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+        const float e = (omax + sc.bvh_cbound) * e_rel;
+        const float p0x = fmaf(tn, dx, ox), p1x = fmaf(tf, dx, ox), p0z = fmaf(tn, dz, oz), p1z = fmaf(tf, dz, oz);
+        const float gmax = (float)(G - 1);
+        const float fx0 = (fminf(p0x, p1x) - e - sc.grid_lo_x) * sc.grid_inv_x, fx1 = (fmaxf(p0x, p1x) + e - sc.grid_lo_x) * sc.grid_inv_x;
+        const float fz0 = (fminf(p0z, p1z) - e - sc.grid_lo_z) * sc.grid_inv_z, fz1 = (fmaxf(p0z, p1z) + e - sc.grid_lo_z) * sc.grid_inv_z;
+        const int i0 = (int)fminf(fmaxf(floorf(fx0), 0.0f), gmax), i1 = (int)fminf(fmaxf(floorf(fx1), 0.0f), gmax);
+        const int j0 = (int)fminf(fmaxf(floorf(fz0), 0.0f), gmax), j1 = (int)fminf(fmaxf(floorf(fz1), 0.0f), gmax);
+        const int wi = i1 - i0, wj = j1 - j0;
+        if (!(wi <= 1 && wj <= 1 && (wi + 1) * (wj + 1) <= sc.grid_kmax)) return; // too many cells (or a NaN): the whole tree, from its root
+        const int *cells = sc.grid_cells;
+        const int a00 = cells[j0 * G + i0], a10 = cells[j0 * G + i1], a01 = cells[j1 * G + i0], a11 = cells[j1 * G + i1]; // four loads in flight (duplicates when the rectangle is narrower)
+        // the cell the segment starts in goes first (its hits prune the others)
+        const int ni = ((int)fminf(fmaxf(floorf((p0x - sc.grid_lo_x) * sc.grid_inv_x), (float)i0), (float)i1)) - i0;
+        const int nj = ((int)fminf(fmaxf(floorf((p0z - sc.grid_lo_z) * sc.grid_inv_z), (float)j0), (float)j1)) - j0;
+        const int k = ni + 2 * nj;
+        near = k == 0 ? a00 : (k == 1 ? a10 : (k == 2 ? a01 : a11));
+        c0 = k == 0 ? RTMI_BVH_EMPTY : a00;
+        c1 = (wi == 0 || k == 1) ? RTMI_BVH_EMPTY : a10;
+        c2 = (wj == 0 || k == 2) ? RTMI_BVH_EMPTY : a01;
+        c3 = (wi == 0 || wj == 0 || k == 3) ? RTMI_BVH_EMPTY : a11;
+    } else if (!(tn > tf)) return; // (a NaN cannot arise for a ray make_bvh_ray accepted; if it did: the whole tree)
+    // else: the ray does not meet the layer's box within its range -- only the tall primitives remain
+    const int stride = blockDim.x;
+    int node = RTMI_BVH_EMPTY, tos = cur.tos, *top = cur.top;
+    auto add = [&](int code) { // the code added last is visited first
+        if (code != RTMI_BVH_EMPTY) {
+            if (node != RTMI_BVH_EMPTY) { *top = tos; top += stride; tos = node; }
+            node = code;
+        }
+    };
+    add(tall); add(c3); add(c2); add(c1); add(c0); add(near);
     cur.node = node; cur.tos = tos; cur.top = top;
 }
 
@@ -1097,6 +1181,9 @@ __device__ inline bool scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, 
     // 2. the tree
     auto leaf = [&](int code) { exact_prim_test_lane<R>(exact12, code, P, qa, tmin, behind_ok, best_t, best_i); };
     auto best = [&]() { return (best_t < R(3.0e38) ? float_up((double)best_t) : 3.4028235e38f) + 0.0f; };
+    if (sc.grid_n && !(SLICE && resume)) // where the traversal starts: the roots of the grid cells the ray's segment crosses, or the root of the whole tree
+        bvh_grid_entry(sc, r, (float)P.ox, (float)P.oy, (float)P.oz, (float)P.dx, (float)P.dy, (float)P.dz, best(),
+                       sizeof(R) == sizeof(float) ? 4.0e-3f + 1.0f / 65536.0f : 1.0f / 65536.0f, cur);
     bvh_traverse<COUNT, SLICE>(sc, r, cur, min_lanes, leaf, best, cnt);
     if (SLICE && cur.node != RTMI_BVH_EMPTY) { // suspended
         int w0, w1;

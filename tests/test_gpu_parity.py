@@ -380,6 +380,61 @@ def tangent_rays(f, n, seed):
     return np.concatenate([o, d, rng.random((n, 1))], axis=1)
 
 
+def grazing_rays(f, n, seed):
+    """adversarial rays for the entry grid (rtmi_device.h: bvh_grid_entry): long, nearly horizontal rays inside and just above the layer
+    of small spheres, rays that run ALONG lines x = const / z = const (cell borders fall on such lines for some grid shape), rays that start
+    on sphere surfaces (as bounced rays do) and leave in every direction, with a few-ulp jitter"""
+    rng = np.random.default_rng(seed)
+    g = f.prim_geom
+    small = g[:, 3] < 50
+    c, rad = g[small, 0:3], g[small, 3]
+    lo, hi = (c - rad[:, None]).min(0), (c + rad[:, None]).max(0)
+    k = n // 4
+    # (a) nearly horizontal, long
+    o = np.stack([rng.uniform(lo[0] - 2, hi[0] + 2, k), rng.uniform(-0.01, 0.6, k), rng.uniform(lo[2] - 2, hi[2] + 2, k)], axis=1)
+    d = np.stack([rng.normal(0, 1, k), rng.normal(0, 1, k) * rng.choice([0.0 + 1e-9, 1e-4, 1e-2, 0.1], k), rng.normal(0, 1, k)], axis=1) * rng.choice([1.0, 1e-3, 50.0], (k, 1))
+    a = np.concatenate([o, d], axis=1)
+    # (b) along axis-parallel lines at "round" coordinates (fractions of the layer's extent: cell borders of many grid shapes)
+    frac = rng.integers(0, 97, k) / rng.choice([2.0, 3.0, 4.0, 5.0, 6.0, 8.0, 12.0, 16.0, 24.0, 32.0, 48.0, 96.0], k)
+    frac = np.clip(frac, 0, 1)
+    along_x = rng.random(k) < 0.5
+    ox = np.where(along_x, rng.uniform(lo[0], hi[0], k), lo[0] + frac * (hi[0] - lo[0]) + rng.choice([0.0, 1e-15, -1e-15, 1e-7, -1e-7, 1e-3], k))
+    oz = np.where(along_x, lo[2] + frac * (hi[2] - lo[2]) + rng.choice([0.0, 1e-15, -1e-15, 1e-7, -1e-7, 1e-3], k), rng.uniform(lo[2], hi[2], k))
+    o = np.stack([ox, rng.uniform(0.0, 0.45, k), oz], axis=1)
+    tiny = rng.choice([1e-9, 1e-6, 1e-3], k) * rng.choice([-1.0, 1.0], k)
+    d = np.stack([np.where(along_x, rng.choice([-1.0, 1.0], k), tiny), rng.normal(0, 0.02, k), np.where(along_x, tiny, rng.choice([-1.0, 1.0], k))], axis=1)
+    b = np.concatenate([o, d], axis=1)
+    # (c) from sphere surfaces (bounced rays), any direction
+    idx = rng.integers(0, len(c), n - 2 * k)
+    nrm = rng.normal(size=(len(idx), 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    o = c[idx] + nrm * rad[idx, None] * (1.0 + rng.choice([0.0, 1e-15, 1e-9, 1e-3], (len(idx), 1)))
+    d = rng.normal(size=(len(idx), 3)) * rng.choice([1.0, 1e-2, 30.0], (len(idx), 1))
+    cc = np.concatenate([o, d], axis=1)
+    rays = np.concatenate([a, b, cc])
+    return np.concatenate([rays, rng.random((len(rays), 1))], axis=1)
+
+
+def layer_scene(seed, n=900, moving=True):
+    """a layer of spheres of mixed radii over the x-z plane with a few tall ones and (optionally) moving ones: what the entry grid is built for,
+    with awkward parameters (overlapping spheres, radii from 0.02 to cell-sized, tall spheres poking through the layer)"""
+    rng = np.random.default_rng(seed)
+    H, S, T = r.hitable, r.shader, r.texture
+    mat = S.lambertian(albedo=T.constant(color=vec3(0.5, 0.5, 0.5)))
+    items = [H.sphere(center=vec3(0, -1000, 0), radius=1000, material=mat)]
+    ext = float(rng.choice([12.0, 40.0]))
+    for k in range(n):
+        rad = float(rng.choice([0.02, 0.1, 0.2, 0.35]))
+        c = vec3(rng.uniform(-ext, ext), rad * float(rng.choice([1.0, 1.0, 0.5, 1.3])), rng.uniform(-ext, ext))
+        if moving and k % 7 == 0:
+            items.append(H.moving_sphere(center0=c, t0=0.0, center1=c + vec3(0, 0.3 * rng.random(), 0.2 * rng.random()), t1=1.0, radius=rad, material=mat))
+        else:
+            items.append(H.sphere(center=c, radius=rad, material=mat))
+    for k in range(4):
+        items.append(H.sphere(center=vec3(rng.uniform(-ext, ext), 1.5, rng.uniform(-ext, ext)), radius=1.5, material=S.dielectric(ri=1.5)))
+    cam = r.camera.thin_lens_camera(lookfrom=vec3(ext, 3, ext * 0.5), lookat=vec3(0, 0, 0), vup=vec3(0, 1, 0), vfov=40, aspect=2.0, aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0)
+    return {"camera": cam, "world": H.hitlist(items=items)}
+
+
 def test_scan_variants_are_bit_identical(oracle, cover11, cover11_moving):
     for sc in (cover11, cover11_moving, r.scene.make_random_scene(64, 32, 50, False)):
         f = fl.flatten(sc)

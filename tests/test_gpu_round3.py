@@ -317,3 +317,47 @@ def test_traversal_counters_of_the_mixed_kind_kernels():
                 ref = (base, trav)
             else:
                 assert np.array_equal(base[0], ref[0][0]) and trav == ref[1], (name, lanes)
+
+
+# ---- the entry grid of the BVH traversal ----------------------------------------------------------------------------------------------------------
+def test_entry_grid_is_bit_identical_to_the_flat_scan(monkeypatch):
+    """rtmi_device.h: bvh_grid_entry -- layer-like sphere scenes get a grid of per-cell BVHs and a ray whose clipped segment stays within a few
+    cells starts its traversal there.  Whatever the grid's shape (RTMI_GRID = cells per side, RTMI_GRID_KMAX = cells a ray may touch), hits
+    must equal the exact Hitlist scan's bit for bit -- on grazing rays, rays along cell borders, rays leaving sphere surfaces, silhouette rays --
+    and so must whole renders and their counters, in both precisions and with moving / tall / overlapping spheres; and the grid must actually
+    shorten traversals (node visits per segment), or it is not being used."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_parity import grazing_rays, tangent_rays, random_rays, layer_scene
+    scenes = [("cover11m", r.scene.make_random_scene(160, 80, 11, True)), ("cover30", r.scene.make_random_scene(160, 80, 30, False)), ("layer", layer_scene(3, n=1200))]
+    for name, sc in scenes:
+        flat = fl.flatten(sc)
+        rays = np.concatenate([grazing_rays(flat, 60000, 11), tangent_rays(flat, 30000, 12), random_rays(10000, 13, spread=40.0)])
+        ref = {}
+        ctx = core.Context(0)
+        ctx.set_option("accel", 0)
+        ds = core.DeviceScene(flat, ctx=ctx)
+        for prec in ("f64", "f32"):
+            ref[prec] = (ds.probe_hit(rays, precision=prec), ds.probe_hit(rays, 0.0, 3.4028234663852886e38, precision=prec), ds.render(160, 80, 8, precision=prec))
+        ds.close(); ctx.close()
+        assert (ref["f64"][0][:, 0] == 1).mean() > 0.2, "the probe rays must hit things"
+        visits = {}
+        for spec in ("0:4", "1:4", "5:1", "23:2", "64:4"):
+            g, k = spec.split(":")
+            monkeypatch.setenv("RTMI_GRID", g)
+            monkeypatch.setenv("RTMI_GRID_KMAX", k)
+            ctx = core.Context(0)
+            ds = core.DeviceScene(flat, ctx=ctx)  # the grid is built with the scene
+            for prec in ("f64", "f32"):
+                a = ds.probe_hit(rays, precision=prec)
+                b = ds.probe_hit(rays, 0.0, 3.4028234663852886e38, precision=prec)
+                assert np.array_equal(a, ref[prec][0], equal_nan=True) and np.array_equal(b, ref[prec][1], equal_nan=True), (name, spec, prec)
+                for lanes in (12, 0):
+                    ctx.set_option("suspend_lanes", lanes)
+                    out = ds.render(160, 80, 8, precision=prec)
+                    for x, y in zip(out, ref[prec][2]):
+                        assert np.array_equal(x, y), (name, spec, prec, lanes)
+            ctx.set_option("count_traversal", 1)
+            out = ds.render(160, 80, 8)
+            visits[spec] = ctx.last_traversal_counters()[0] / 2 / float(out[2][0])
+            ds.close(); ctx.close()
+        assert visits["1:4"] < 0.8 * visits["0:4"], (name, visits)
