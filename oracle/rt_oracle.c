@@ -139,7 +139,12 @@ static inline v3 point_at(const ray_t *r, real t) { return vadd(vscale(r->d, t),
 
 /* ---- counter-based random stream (introduced by this build; replaces clojure.core/rand) ---- */
 #define GOLD 0x9E3779B97F4A7C15ULL
-static inline uint64_t mix64(uint64_t z) { /* splitmix64 finaliser */
+static inline uint64_t mix64(uint64_t z) { /* the stream's mixer ("degski64": shifts of 32 cost a 32-bit ALU nothing), DESIGN.md section 2 */
+    z ^= z >> 32; z *= 0xD6E8FEB86659FD93ULL;
+    z ^= z >> 32; z *= 0xD6E8FEB86659FD93ULL;
+    z ^= z >> 32; return z;
+}
+static inline uint64_t splitmix64_fin(uint64_t z) { /* splitmix64 finaliser: the axis choice of this file's own make-bvh (below), as in rounds 1-2 */
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
     z ^= z >> 27; z *= 0x94D049BB133111EBULL;
     z ^= z >> 31; return z;
@@ -875,7 +880,7 @@ static void ent_bbox(bvhb_t *c, int e, double *mn, double *mx) {
 }
 static int bvh_build(bvhb_t *c, int *list, int n) { /* hitable.clj:108-123 make-bvh (axis from our own stream) */
     c->rs += GOLD;
-    c->axis = (int)(mix64(c->rs) % 3);
+    c->axis = (int)(splitmix64_fin(c->rs) % 3);
     g_sort_ctx = c;
     qsort(list, (size_t)n, sizeof(int), cmp_axis);
     int L, R;

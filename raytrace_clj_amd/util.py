@@ -24,8 +24,8 @@ def point_at_parameter(r, t):
 
 class SplitMix64:
     """Seeded host stream for scene construction (the reference uses the unseeded global
-    clojure.core/rand there, scene.clj:369-405).  Same mixer as the
-    device stream (include/rtmi.h, rtmi_sample_key)."""
+    clojure.core/rand there, scene.clj:369-405): splitmix64.  (The RENDER stream -- sample_key /
+    draw_bits below, rtmi_sample_key -- has its own mixer since round 3; scenes did not change with it.)"""
 
     MASK = (1 << 64) - 1
     GOLD = 0x9E3779B97F4A7C15
@@ -56,13 +56,25 @@ class SplitMix64:
         return self.next_u64() % n
 
 
+def mix64(z):
+    """the render stream's mixer (rtmi_device.h mix64): two rounds of x ^= x >> 32; x *= 0xD6E8FEB86659FD93, then x ^= x >> 32"""
+    m = SplitMix64.MASK
+    z &= m
+    z ^= z >> 32
+    z = (z * 0xD6E8FEB86659FD93) & m
+    z ^= z >> 32
+    z = (z * 0xD6E8FEB86659FD93) & m
+    z ^= z >> 32
+    return z
+
+
 def sample_key(seed, pixel, sample):
     """Stream key of (seed, pixel index j*nx+i, sample) -- python restatement of rtmi_sample_key."""
     m, g = SplitMix64.MASK, SplitMix64.GOLD
-    a = SplitMix64.mix64((seed ^ (g * (pixel + 1))) & m)
-    return SplitMix64.mix64((a + 0xD1B54A32D192ED03 * (sample + 1)) & m)
+    a = mix64((seed ^ (g * (pixel + 1))) & m)
+    return mix64((a + 0xD1B54A32D192ED03 * (sample + 1)) & m)
 
 
 def draw_bits(key, d):
     m, g = SplitMix64.MASK, SplitMix64.GOLD
-    return SplitMix64.mix64((key + g * (d + 1)) & m)
+    return mix64((key + g * (d + 1)) & m)

@@ -893,7 +893,10 @@ def test_media_match_oracle(oracle):
             assert np.array_equal(log[same][:, :, 0], elog[same][:, :, 0]) and np.allclose(log[same], elog[same], rtol=1e-9, atol=1e-9), (name, accel)
             assert np.allclose(rgb[same], ergb[same], atol=1e-9, rtol=0)
             lin, q, cnt = ds.render(nx, ny, ns)
-            assert abs(int(cnt[0]) - int(exp_cnt[0])) <= 2 + 1e-5 * int(exp_cnt[0]) and rms(lin, exp_lin) <= RMS_TOL, (name, accel, rms(lin, exp_lin))
+            # total-rays: a free-flight distance that lands within an ulp of the chord (ocml log vs glibc log) sends ONE path of the frame a
+            # different way -- up to depth 50 segments of it (round 3's stream: one sample of make-final at pixel (8, 35), 131 vs 115 segments,
+            # both black; BVH and flat scan agree with each other bit for bit there).  One path's worth of slack, no more.
+            assert abs(int(cnt[0]) - int(exp_cnt[0])) <= 52 + 1e-5 * int(exp_cnt[0]) and rms(lin, exp_lin) <= RMS_TOL, (name, accel, rms(lin, exp_lin))
         ds.close(); ctx.close()
         if name == "final":
             media = np.flatnonzero((f.prim_kind[:f.n_prims] & 15) == 7)

@@ -240,6 +240,33 @@ def test_rng_matches_python_restatement(oracle):
     assert [g.next_u64() for _ in range(3)] == [6457827717110365317, 3203168211198807973, 9817491932198370423]
 
 
+def test_stream_mixer_avalanche():
+    """the render stream's mixer (two rounds of x ^= x >> 32; x *= 0xD6E8FEB86659FD93, then x ^= x >> 32 -- it replaced the splitmix64 finaliser in
+    round 3 because shifts by 32 are free on a 32-bit ALU): flipping any input bit flips every output bit with probability 1/2 to within the
+    sampling noise, on random inputs and on the Weyl sequence key + GOLD * d the stream feeds it -- the same figures as the finaliser's
+    (scripts/rng_quality.py prints both, and the one-multiply mixer that was rejected: rms 0.25)"""
+    def mix(z):
+        z = z.copy()
+        for _ in range(2):
+            z ^= z >> np.uint64(32)
+            z *= np.uint64(0xD6E8FEB86659FD93)
+        z ^= z >> np.uint64(32)
+        return z
+    from raytrace_clj_amd.util import mix64
+    n = 40000
+    rng = np.random.default_rng(3)
+    with np.errstate(over="ignore"):
+        assert [int(v) for v in mix(np.array([0, 1, 0x5EED0002, 2 ** 64 - 1], np.uint64))] == [mix64(0), mix64(1), mix64(0x5EED0002), mix64(2 ** 64 - 1)]
+        for x in (rng.integers(0, 2 ** 64, n, dtype=np.uint64), np.uint64(0x1234567) + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, n + 1, dtype=np.uint64)):
+            fx = mix(x)
+            dev = np.zeros((64, 64))
+            for i in range(64):
+                d = fx ^ mix(x ^ np.uint64(1 << i))
+                dev[i] = [(((d >> np.uint64(j)) & np.uint64(1)).mean() - 0.5) for j in range(64)]
+            noise = 0.5 / np.sqrt(n)
+            assert np.sqrt((dev ** 2).mean()) < 1.15 * noise and np.abs(dev).max() < 5.5 * noise
+
+
 def test_rng_uniformity(oracle):
     k = oracle.sample_key(1, 2, 3)
     x = np.array([oracle.draw(k, d) for d in range(20000)])
