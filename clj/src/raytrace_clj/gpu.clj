@@ -50,36 +50,43 @@
 
 (defn- v3 [v] [(mat/mget v 0) (mat/mget v 1) (mat/mget v 2)])
 
+(def ^:private media-modes (atom #{}))   ; how flatten-scene's walk reached the media: :descent (bvh-nodes only above) / :hitlist (Hitlists only above)
+
 (defprotocol GpuLeaves
-  (leaves [this chain flip in-list?]
+  (leaves [this chain flip in-list? under-bvh?]
     "[{:leaf record :chain [[kind a b c] ...] :flip 0|1} ...] below this Hitable, in the order (and as often as) the
     reference's descent calls hit? on them; chain = the Translate / RotateY wrappers around the leaf, outermost first
     (kind 0 = translate offset.xyz, 1 = rotate-y sin cos 0).  A one-item make-bvh node holds the same child twice
     (hitable.clj:113-114) and is therefore listed twice: dedup-leaves drops the repeats for the primitive table, the
-    repeats of ConstantMedium records are kept as the media call sequence."))
+    repeats of ConstantMedium records are kept as the media call sequence.  in-list? / under-bvh?: a Hitlist / a bvh-node is among the
+    ancestors -- a medium's hit? draws inside, so it matters whether its t-max comes narrowed by the siblings before it (Hitlist.hit?,
+    hitable.clj:15-26: rtmi_scene_set_media_mode RTMI_MEDIA_HITLIST) or un-narrowed (bvh-node.hit?, hitable.clj:99-105); both at once is
+    not supported."))
 
 (defn- leaf [this chain flip] [{:leaf this :chain chain :flip flip}])
 
 (extend-protocol GpuLeaves
-  Hitlist      (leaves [this c f l] (mapcat #(leaves % c f true) (:items this)))                        ; hitable.clj:15-26
-  bvh_node     (leaves [this c f l] (concat (leaves (:left this) c f l) (leaves (:right this) c f l)))   ; hitable.clj:97-105
-  Box          (leaves [this c f l] (leaves (:sides this) c f false))                                    ; hitable.clj:491-494
-  FlipNormals  (leaves [this c f l] (leaves (:item this) c (bit-xor f 1) l))                             ; hitable.clj:375-381
-  Translate    (leaves [this c f l] (leaves (:item this) (conj c (into [0.0] (v3 (:offset this)))) f l)) ; hitable.clj:391-396
-  RotateY      (leaves [this c f l] (leaves (:obj this) (conj c [1.0 (:sin-theta this) (:cos-theta this) 0.0]) f l)) ; :410-450
-  ConstantMedium (leaves [this c f l]                                                                    ; hitable.clj:516-541
-                   (when l (throw (ex-info "ConstantMedium inside a Hitlist is not supported on the GPU path"
-                                           {:unsupported-on-gpu-path ConstantMedium})))
+  Hitlist      (leaves [this c f l b] (doall (mapcat #(leaves % c f true b) (:items this))))                   ; hitable.clj:15-26
+  bvh_node     (leaves [this c f l b] (doall (concat (leaves (:left this) c f l true) (leaves (:right this) c f l true)))) ; hitable.clj:97-105
+  Box          (leaves [this c f l b] (leaves (:sides this) c f l b))   ; hitable.clj:491-494: (hit? sides ...) with the caller's interval
+  FlipNormals  (leaves [this c f l b] (leaves (:item this) c (bit-xor f 1) l b))                             ; hitable.clj:375-381
+  Translate    (leaves [this c f l b] (leaves (:item this) (conj c (into [0.0] (v3 (:offset this)))) f l b)) ; hitable.clj:391-396
+  RotateY      (leaves [this c f l b] (leaves (:obj this) (conj c [1.0 (:sin-theta this) (:cos-theta this) 0.0]) f l b)) ; :410-450
+  ConstantMedium (leaves [this c f l b]                                                                      ; hitable.clj:516-541
+                   (when (and l b)
+                     (throw (ex-info "a ConstantMedium inside a Hitlist below a bvh-node is not supported on the GPU path"
+                                     {:unsupported-on-gpu-path ConstantMedium})))
+                   (swap! media-modes conj (if l :hitlist :descent))
                    (leaf this c f))
-  Sphere       (leaves [this c f l] (leaf this c f))
-  UVSphere     (leaves [this c f l] (leaf this c f))
-  MovingSphere (leaves [this c f l] (leaf this c f))
-  RectXY       (leaves [this c f l] (leaf this c f))
-  RectXZ       (leaves [this c f l] (leaf this c f))
-  RectYZ       (leaves [this c f l] (leaf this c f))
-  Triangle     (leaves [this c f l] (leaf this c f))
-  Object       (leaves [this c f l] (throw (ex-info (str (type this) " is not supported on the GPU path")
-                                                    {:unsupported-on-gpu-path (type this)}))))
+  Sphere       (leaves [this c f l b] (leaf this c f))
+  UVSphere     (leaves [this c f l b] (leaf this c f))
+  MovingSphere (leaves [this c f l b] (leaf this c f))
+  RectXY       (leaves [this c f l b] (leaf this c f))
+  RectXZ       (leaves [this c f l b] (leaf this c f))
+  RectYZ       (leaves [this c f l b] (leaf this c f))
+  Triangle     (leaves [this c f l b] (leaf this c f))
+  Object       (leaves [this c f l b] (throw (ex-info (str (type this) " is not supported on the GPU path")
+                                                      {:unsupported-on-gpu-path (type this)}))))
 
 (defn- leaf-id-fn
   "object IDENTITY -> small integer (an IdentityHashMap, not System/identityHashCode: that is a 31-bit hash and two of the
@@ -163,7 +170,11 @@
   "{:camera c :world w} -> the flat arrays of include/rtmi.h (as Clojure primitive arrays)"
   [{:keys [camera world]}]
   (reset! images [])
-  (let [called    (vec (leaves world [] 0 false))          ; hit? invocation order, repeats included
+  (reset! media-modes #{})
+  (let [called    (vec (leaves world [] 0 false false))    ; hit? invocation order, repeats included
+        _         (when (> (count @media-modes) 1)
+                    (throw (ex-info "media reached through a Hitlist and media reached through bvh-nodes only in one world: not supported on the GPU path"
+                                    {:unsupported-on-gpu-path ConstantMedium})))
         lid       (leaf-id-fn)
         world-es  (dedup-leaves lid called)
         key-of    (fn [e] [(lid (:leaf e)) (:chain e) (:flip e)])
@@ -172,7 +183,7 @@
         ;; every medium's boundary is flattened on its own and appended AFTER the world (kind | 16)
         bounds    (reduce (fn [acc [i e]]
                             (if (instance? ConstantMedium (:leaf e))
-                              (let [b (dedup-leaves (leaf-id-fn) (leaves (:boundary (:leaf e)) (:chain e) (:flip e) false))]
+                              (let [b (dedup-leaves (leaf-id-fn) (leaves (:boundary (:leaf e)) (:chain e) (:flip e) false false))]
                                 (-> acc
                                     (assoc-in [:range i] [(+ (count world-es) (count (:prims acc))) (count b)])
                                     (update :prims into b)))
@@ -224,6 +235,7 @@
      :xform-kind  (int-array (map #(int (first %)) xforms))
      :xform-param (double-array (mapcat rest xforms))
      :media-calls (int-array media-calls)
+     :media-mode  (int (if (= @media-modes #{:hitlist}) 1 0))   ; RTMI_MEDIA_HITLIST: the world is a Hitlist, its narrowing reaches the media
      :uses-perlin (boolean (some #(#{3 4 5} (:kind %)) trows))
      :images      @images}))
 
@@ -262,6 +274,8 @@
       (when (pos? (alength ^ints (:media-calls f)))
         (let [calls (:media-calls f)]
           (check (call-int "rtmi_scene_set_media_calls" scene (int (alength ^ints calls)) calls))))
+      (when (pos? (:media-mode f))
+        (check (call-int "rtmi_scene_set_media_mode" scene (int (:media-mode f)))))
       scene)))
 
 (defn render

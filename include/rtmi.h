@@ -125,8 +125,8 @@ int rtmi_scene_create(rtmi_ctx *ctx,
  *                     xform table, OUTERMOST FIRST;  xform_kind[k] = RTMI_XFORM_*;
  *   xform_param[k*3..] Translate: offset.xyz | RotateY: sin-theta, cos-theta, 0 (the record's fields, hitable.clj:410).
  * Box (hitable.clj:491) flattens to its six rectangles.  ConstantMedium (hitable.clj:516-541) draws its random number inside
- * hit?: media are evaluated in primitive-index order with the un-narrowed (t-min, t-max) of the reference's bvh-node descent,
- * so a world must not enclose a medium in a Hitlist (no scene of scene.clj does); at most 16 media per scene.  Scenes that use
+ * hit?: by default media are evaluated in primitive-index order with the un-narrowed (t-min, t-max) of the reference's bvh-node descent;
+ * a world that IS a Hitlist holding media is declared with rtmi_scene_set_media_mode(RTMI_MEDIA_HITLIST); at most 16 media per scene.  Scenes that use
  * any of this are rendered by the FP64 kernels only (RTMI_F32 -> RTMI_E_UNSUPPORTED). */
 int rtmi_scene_create_ex(rtmi_ctx *ctx,
                          int32_t n_prims, const int32_t *prim_kind, const double *prim_geom, const int32_t *prim_mat,
@@ -147,6 +147,16 @@ int rtmi_scene_set_images(rtmi_scene *scene, int32_t n_images, const int32_t *wh
  * stores a lone item as bvh-node(L, L), hitable.clj:113-114, and bvh-node.hit? evaluates both children: a medium there is
  * asked twice, draws two random numbers and the nearer scattering point wins.) */
 int rtmi_scene_set_media_calls(rtmi_scene *scene, int32_t n_calls, const int32_t *calls);
+/* How a ConstantMedium's hit? is called (it draws its random number INSIDE hit?, hitable.clj:529, so the t-max it is handed matters):
+ *   RTMI_MEDIA_DESCENT (default)  the world is a make-bvh tree: bvh-node.hit? hands both children the un-narrowed (t-min, t-max)
+ *                                 (hitable.clj:99-105); the media are evaluated after the surfaces, in call order (rtmi_scene_set_media_calls);
+ *   RTMI_MEDIA_HITLIST            the world is a Hitlist (nested Hitlists / Boxes / instance wrappers spliced in item order, no bvh-node
+ *                                 anywhere): Hitlist.hit? hands every item the t-max narrowed by the items BEFORE it (hitable.clj:15-26), so
+ *                                 a medium is evaluated at its place in the list with the closest hit so far as its t-max; the primitives
+ *                                 must be in list order and every medium is called once, in ascending index order.
+ * A world that mixes the two (a Hitlist holding media below a bvh-node) is not supported: the flatteners raise "unsupported on GPU path". */
+enum { RTMI_MEDIA_DESCENT = 0, RTMI_MEDIA_HITLIST = 1 };
+int rtmi_scene_set_media_mode(rtmi_scene *scene, int32_t mode);
 int rtmi_scene_destroy(rtmi_scene *scene);
 
 /* ---- the hot path --------------------------------------------------------------------------- */

@@ -117,6 +117,8 @@ class DeviceScene:
         if calls is not None and len(calls):  # ConstantMedium hit? invocation order (a medium in a one-item bvh leaf is asked twice)
             calls = np.ascontiguousarray(calls, np.int32)
             check(_ffi.lib().rtmi_scene_set_media_calls(h, len(calls), ptr(calls)))
+        if getattr(f, "media_mode", 0):  # the world is a Hitlist holding media: their hit? sees the t-max narrowed by the items before them
+            check(_ffi.lib().rtmi_scene_set_media_mode(h, int(f.media_mode)))
         images = getattr(f, "images", None) or []
         if images:  # ImageMap pixels (texture.clj:126-133)
             imgs = [np.ascontiguousarray(im, np.uint8) for im in images]

@@ -124,13 +124,33 @@ __device__ inline void scan_cull_dispatch(SceneRef sc, const Path<float> &P, flo
 // hit? of the whole world for the lane's ray (closest hit, t in (t-min, t-max); core.clj:25 passes 0.001, Float/MAX_VALUE).
 // MULTI (LDS variants only): the static spheres do not fit one LDS tile; every thread of the workgroup must call this.
 // section 8(f3) scenes (FP64 only): BVH or culled flat scan over mixed primitive kinds with the any-order tie rule
-template <bool SLICED = false, bool COUNT = false>
+// MSEQ: the instantiations for RTMI_MEDIA_HITLIST worlds (their own kernels: the plain mixed-kind kernels keep their registers)
+template <bool SLICED = false, bool COUNT = false, bool MSEQ = false>
 __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<double> &P, bool active, double tmin, double tmax, double &best_t, int &best_i,
                                      bool *mid = nullptr, int min_lanes = 0, unsigned *cnt = nullptr) {
     best_t = tmax; best_i = -1;
     if (!active) return;
     const double a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
     ExtHit H = {tmax, 0x7fffffff, -1, false};
+    if (MSEQ) {
+        // RTMI_MEDIA_HITLIST: the world is a Hitlist (hitable.clj:15-26: (hit? item r t-min closest-so-far), item after item).  Surfaces may be
+        // folded in any order (ExtHit reproduces the list's tie rule), so the list is scanned in pieces: the surfaces before the first medium,
+        // that medium with the t-max the list would hand it -- the closest hit so far --, the surfaces up to the next medium, and so on.  (These
+        // scenes run the instantiation without time-slicing: media_seq and SLICED never meet.)
+        int prev = 0;
+        for (int k = 0; k <= sc.n_media; ++k) {
+            const int m = k < sc.n_media ? sc.media_idx[k] : sc.n_all;
+            if (m > prev) {
+                if (bvh) scan_bvh_ext<false, COUNT>(sc, stack, P, a, tmin, H, nullptr, false, 0, cnt, prev, m);
+                else scan_all_cull_ext(sc, P, a, tmin, H, prev, m);
+            }
+            if (k < sc.n_media) ext_medium_test(sc, m, P, tmin, H.any ? H.t : tmax, H, COUNT ? cnt : nullptr);
+            prev = m + 1;
+        }
+        best_i = ext_winner(H);
+        if (best_i >= 0) best_t = H.t;
+        return;
+    }
     if (bvh) {
         if (SLICED) { // time-sliced: a suspended lane's media are evaluated (and draw) when its traversal completes, as in the plain loop
             const bool done = scan_bvh_ext<true, COUNT>(sc, stack, P, a, tmin, H, stack + RTMI_BVH_STACK * blockDim.x, *mid, min_lanes, cnt);
@@ -143,13 +163,13 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
     best_i = ext_winner(H);
     if (best_i >= 0) best_t = H.t;
 }
-template <bool SLICED = false, bool COUNT = false>
+template <bool SLICED = false, bool COUNT = false, bool MSEQ = false>
 __device__ inline void intersect_ext(SceneRef, int *, bool, Path<float> &, bool, float, float tmax, float &best_t, int &best_i, bool * = nullptr, int = 0, unsigned * = nullptr) { best_t = tmax; best_i = -1; }
 
-template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICED = false>
+template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICED = false, bool MSEQ = false>
 __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, Path<R> &P,
                                        bool active, R tmin, R tmax, R &best_t, int &best_i, unsigned *cnt = nullptr, bool *mid = nullptr, int min_lanes = 0) {
-    if (EXT) { intersect_ext<SLICED, COUNT>(sc, reinterpret_cast<int *>(lds), VARIANT == SCAN_BVH, P, active, tmin, tmax, best_t, best_i, mid, min_lanes, cnt); return; }
+    if (EXT) { intersect_ext<SLICED, COUNT, MSEQ>(sc, reinterpret_cast<int *>(lds), VARIANT == SCAN_BVH, P, active, tmin, tmax, best_t, best_i, mid, min_lanes, cnt); return; }
     best_t = tmax;
     best_i = -1;
     const R a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
@@ -211,7 +231,7 @@ template <typename R> __device__ inline void start_sample(SceneRef sc, const Tra
 }
 
 // SLICE: time-sliced BVH traversal (section 5.1b of DESIGN.md); the plain instantiation is kept for scenes whose tree is too small to gain
-template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICE = true>
+template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICE = true, bool MSEQ = false>
 __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
     SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -346,8 +366,8 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
         // are `mid` segment -- they sit out the shading below and resume where they stopped in the next trip, next to the new
         // segments of the others.  Once the queue is empty nothing is gained by handing back early (suspend_lanes 0).
         R best_t; int best_i;
-        intersect_world<R, MULTI, VARIANT, EXT, COUNT, SLICED>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i, ntrav,
-                                                               &mid, exhausted ? 0 : tp.suspend_lanes);
+        intersect_world<R, MULTI, VARIANT, EXT, COUNT, SLICED, MSEQ>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i, ntrav,
+                                                                     &mid, exhausted ? 0 : tp.suspend_lanes);
         RTMI_PH(PH_BVH_POST) // intersection: what the phases inside did not book (suspend bookkeeping, call overhead)
         if (!SLICED || __any(alive && !mid)) { // a trip in which no lane finished its segment has nothing to shade
         if (alive) {
@@ -479,7 +499,7 @@ template <typename R> __device__ inline void load_ray(const double *q, Path<R> &
     P.ar = P.ag = P.ab = R(1); seed_stream(P, 0ull, 0u); P.depth = 0;
 }
 
-template <typename R, int VARIANT, bool EXT = false>
+template <typename R, int VARIANT, bool EXT = false, bool MSEQ = false>
 __global__ void __launch_bounds__(kBlock) probe_hit_kernel(ScenePtr scp, int prims_per_tile, int n_ptiles, int n, const double *rays, double tmin, double tmax, double *out) {
     SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -489,7 +509,7 @@ __global__ void __launch_bounds__(kBlock) probe_hit_kernel(ScenePtr scp, int pri
     Path<R> P;
     load_ray<R>(rays + (size_t)(active ? k : 0) * 7, P);
     R best_t; int best_i;
-    intersect_world<R, true, VARIANT, EXT>(sc, lds, prims_per_tile, n_ptiles, P, active, (R)tmin, (R)tmax, best_t, best_i);
+    intersect_world<R, true, VARIANT, EXT, false, false, MSEQ>(sc, lds, prims_per_tile, n_ptiles, P, active, (R)tmin, (R)tmax, best_t, best_i);
     if (!active) return;
     double *o = out + (size_t)k * 11;
     for (int c = 0; c < 11; ++c) o[c] = 0.0;
@@ -500,7 +520,7 @@ __global__ void __launch_bounds__(kBlock) probe_hit_kernel(ScenePtr scp, int pri
     o[6] = h.nx; o[7] = h.ny; o[8] = h.nz; o[9] = h.u; o[10] = h.v;
 }
 
-template <typename R, int VARIANT, bool EXT = false>
+template <typename R, int VARIANT, bool EXT = false, bool MSEQ = false>
 __global__ void __launch_bounds__(kBlock) probe_paths_kernel(ScenePtr scp, int prims_per_tile, int n_ptiles, int n, const double *rays, const u64 *keys, u64 ctr0,
                                                              int depth, double *out_rgb, u64 *out_nseg, double *log, int max_seg, int *out_nlog) {
     SceneRef sc = *scp;
@@ -517,7 +537,7 @@ __global__ void __launch_bounds__(kBlock) probe_paths_kernel(ScenePtr scp, int p
     R rgb[3] = {R(0), R(0), R(0)};
     while (__syncthreads_or(alive ? 1 : 0)) {
         R best_t; int best_i;
-        intersect_world<R, true, VARIANT, EXT>(sc, lds, prims_per_tile, n_ptiles, P, alive, tmin, tmax, best_t, best_i);
+        intersect_world<R, true, VARIANT, EXT, false, false, MSEQ>(sc, lds, prims_per_tile, n_ptiles, P, alive, tmin, tmax, best_t, best_i);
         if (alive) {
             ++nseg;
             R emit[3];
@@ -700,6 +720,7 @@ struct rtmi_scene {
         std::vector<double> prim_geom, mat_param, tex_param, cam, xform_param, perlin_vec;
         std::vector<uint8_t> image_rgb;
         int cam_kind = 0;
+        int media_mode = 0;
         bool has_media_calls = false;
     } args;
 };
@@ -859,7 +880,12 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         const size_t bvh_lds = (size_t)(RTMI_BVH_STACK + RTMI_BVH_SUSPEND_WORDS) * kTraceBlock * sizeof(int); // stack columns + suspended cursors
         tp.suspend_lanes = c->suspend_lanes;
         if (const char *e = std::getenv("RTMI_SUSPEND_LANES")) tp.suspend_lanes = std::max(0, std::min(64, std::atoi(e)));
-        if (s->dev.has_ext) { // section 8(f3) scenes: FP64 kernels with the mixed-kind intersectors
+        if (s->dev.has_ext && s->dev.media_seq) { // a Hitlist world holding media (RTMI_MEDIA_HITLIST): its own instantiations, never time-sliced
+            if (variant == SCAN_BVH) {
+                kern = c->count_traversal ? trace_kernel<double, false, SCAN_BVH, true, true, false, true> : trace_kernel<double, false, SCAN_BVH, true, false, false, true>;
+                dyn_lds = (size_t)RTMI_BVH_STACK * kTraceBlock * sizeof(int);
+            } else kern = trace_kernel<double, false, SCAN_SGPR_CULL, true, false, true, true>;
+        } else if (s->dev.has_ext) { // section 8(f3) scenes: FP64 kernels with the mixed-kind intersectors
             if (variant == SCAN_BVH) { // a Cornell box's 20-primitive tree loses 5 % to the time-slicing machinery, make-final's 3400 gain 8 %
                 const bool slice = s->bvh_node_count >= 128 && tp.suspend_lanes > 0;
                 if (c->count_traversal) kern = slice ? trace_kernel<double, false, SCAN_BVH, true, true> : trace_kernel<double, false, SCAN_BVH, true, true, false>;
@@ -1774,9 +1800,23 @@ RTMI_EXPORT int rtmi_scene_set_media_calls(rtmi_scene *s, int32_t n_calls, const
     if (n_calls < 0 || n_calls > 32 || (n_calls > 0 && !calls)) return fail(RTMI_E_ARG, "n_calls must be 0..32");
     for (int k = 0; k < n_calls; ++k)
         if (calls[k] < 0 || calls[k] >= s->n_prims || s->host_kind[(size_t)calls[k]] != RTMI_PRIM_MEDIUM) return fail(RTMI_E_ARG, "calls[%d] = %d is not a medium primitive", k, calls[k]);
+    if (s->dev.media_seq)
+        for (int k = 1; k < n_calls; ++k) if (calls[k] <= calls[k - 1]) return fail(RTMI_E_ARG, "RTMI_MEDIA_HITLIST: the media must be called once each, in ascending primitive (= list) order");
     s->dev.n_media = n_calls;
     for (int k = 0; k < n_calls; ++k) s->dev.media_idx[k] = calls[k];
     s->args.media_calls.assign(calls, calls + n_calls); s->args.has_media_calls = true;
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    return reupload_descriptor(s);
+}
+
+RTMI_EXPORT int rtmi_scene_set_media_mode(rtmi_scene *s, int32_t mode) {
+    if (!scene_ok(s)) return fail(RTMI_E_STATE, "invalid scene handle");
+    if (mode != RTMI_MEDIA_DESCENT && mode != RTMI_MEDIA_HITLIST) return fail(RTMI_E_ARG, "mode must be RTMI_MEDIA_DESCENT or RTMI_MEDIA_HITLIST");
+    if (mode == RTMI_MEDIA_HITLIST)
+        for (int k = 1; k < s->dev.n_media; ++k)
+            if (s->dev.media_idx[k] <= s->dev.media_idx[k - 1]) return fail(RTMI_E_ARG, "RTMI_MEDIA_HITLIST: the media must be called once each, in ascending primitive (= list) order");
+    s->dev.media_seq = mode == RTMI_MEDIA_HITLIST ? 1 : 0;
+    s->args.media_mode = mode;
     HIP_TRY(hipSetDevice(s->ctx->device));
     return reupload_descriptor(s);
 }
@@ -1917,6 +1957,7 @@ RTMI_EXPORT int rtmi_scene_clone(rtmi_scene *src, rtmi_ctx *ctx, rtmi_scene **ou
     if (!rc && !A.perlin_vec.empty()) rc = rtmi_scene_set_perlin(s, A.perlin_vec.data(), A.perm.data());
     if (!rc && !A.image_wh.empty()) rc = rtmi_scene_set_images(s, (int32_t)(A.image_wh.size() / 2), A.image_wh.data(), A.image_rgb.data());
     if (!rc && A.has_media_calls) rc = rtmi_scene_set_media_calls(s, (int32_t)A.media_calls.size(), A.media_calls.data());
+    if (!rc && A.media_mode) rc = rtmi_scene_set_media_mode(s, A.media_mode);
     if (rc) { const std::string keep = g_err; rtmi_scene_destroy(s); g_err = keep; return rc; }
     *out_scene = s;
     return RTMI_OK;
@@ -2269,8 +2310,9 @@ RTMI_EXPORT int rtmi_probe_hit(rtmi_scene *s, int32_t precision, int32_t n, cons
     if (precision == RTMI_F64) {
         lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
         if (s->dev.has_ext) {
-            if (c->accel == RTMI_ACCEL_BVH) hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_BVH, true>), dim3(grid), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
-            else hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_SGPR_CULL, true>), dim3(grid), dim3(kBlock), 64, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
+            const bool seq = s->dev.media_seq != 0;
+            if (c->accel == RTMI_ACCEL_BVH) hipLaunchKernelGGL((seq ? probe_hit_kernel<double, SCAN_BVH, true, true> : probe_hit_kernel<double, SCAN_BVH, true>), dim3(grid), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
+            else hipLaunchKernelGGL((seq ? probe_hit_kernel<double, SCAN_SGPR_CULL, true, true> : probe_hit_kernel<double, SCAN_SGPR_CULL, true>), dim3(grid), dim3(kBlock), 64, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
         } else
         switch (c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant) {
         case SCAN_BVH: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_BVH>), dim3(grid), dim3(kBlock), std::max(lds, (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16), c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
@@ -2313,8 +2355,9 @@ RTMI_EXPORT int rtmi_probe_paths(rtmi_scene *s, int32_t precision, int32_t n, co
     if (precision == RTMI_F64) {
         lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
         if (s->dev.has_ext) {
-            if (c->accel == RTMI_ACCEL_BVH) hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_BVH, true>), dim3(grid), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
-            else hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_SGPR_CULL, true>), dim3(grid), dim3(kBlock), 64, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
+            const bool seq = s->dev.media_seq != 0;
+            if (c->accel == RTMI_ACCEL_BVH) hipLaunchKernelGGL((seq ? probe_paths_kernel<double, SCAN_BVH, true, true> : probe_paths_kernel<double, SCAN_BVH, true>), dim3(grid), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
+            else hipLaunchKernelGGL((seq ? probe_paths_kernel<double, SCAN_SGPR_CULL, true, true> : probe_paths_kernel<double, SCAN_SGPR_CULL, true>), dim3(grid), dim3(kBlock), 64, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
         } else
         switch (c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant) {
         case SCAN_BVH: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_BVH>), dim3(grid), dim3(kBlock), std::max(lds, (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16), c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;

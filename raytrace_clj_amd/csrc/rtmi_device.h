@@ -55,6 +55,7 @@ struct DevScene {
     int has_ext;             // any primitive kind > 2, any instance wrapper, any flip
     const int *ext_info;     // [n_all][4]: kind, FlipNormals parity, first xform, xform count (outermost first)
     const double *ext_xf;    // [n_xforms][4]: 0 | offset.xyz  (Translate)   or   1 | sin, cos, 0  (RotateY)
+    int media_seq;           // RTMI_MEDIA_HITLIST: the world is a Hitlist (hitable.clj:15-26), a medium's hit? sees the t-max narrowed by the items before it
     int n_media;             // hit? invocations of ConstantMedium primitives (hitable.clj:516) per ray, in the reference's call order
     int media_idx[32];       // (a medium may appear twice: rtmi_scene_set_media_calls); exact12 = density, first boundary prim, count
     // section 8(f4): perlin.clj:6-17 tables (seeded scene data) and ImageMap pixels (texture.clj:126-133)
@@ -827,6 +828,9 @@ __device__ inline void scan_all_cull(SceneRef sc, const Path<double> &P, double 
 // ---- RTMI_ACCEL_BVH: per-lane BVH traversal with conservative float boxes, exact FP64 leaves -------------------------
 // Closest hit is order independent: candidate(prim) = first root if > t-min else second root (hitable.clj:192-207 with the
 // running t-max of hitable.clj:20 only ever rejecting non-minimal candidates); ties -> lowest Hitlist index (first wins).
+#ifndef RTMI_GRID_NEAR
+#define RTMI_GRID_NEAR 0 // 1: the cell a segment starts in is visited first (its hits would prune the others) -- measured: the ordering's own instructions cost more than the pruning saves (C3 77.9 vs 77.6 ms without)
+#endif
 #ifndef RTMI_EXIT_IBALLOT
 #define RTMI_EXIT_IBALLOT 1
 #endif
@@ -1076,8 +1080,8 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, const BvhRay &r, BvhCursor 
 // boxes of the top ten levels nearly all contain a ray that starts inside the scene.  The layer of primitives is cut into x-z cells with a
 // BVH each; the ray's parameter range inside the layer's box (the slab test of one more box, with the constants of make_bvh_ray, cut at the
 // closest hit so far -- the ground, usually) gives a segment, the segment's end points a rectangle of cells.  If that rectangle is at most
-// 2 x 2 cells and grid_kmax cells, the traversal starts with those cells' roots (nearest first) and the tall primitives' tree on the
-// stack; otherwise at the root of the whole tree.  Every primitive the ray can hit within its range overlaps one of those cells or is tall:
+// 2 x 2 cells and grid_kmax cells, the traversal starts with those cells' roots and -- if the ray meets their box -- the tall primitives' tree on
+// the stack; otherwise at the root of the whole tree.  Every primitive the ray can hit within its range overlaps one of those cells or is tall:
 // the end points carry a float error below 2^-21 (|o| + cbound) and the rectangle is grown by 2^-16 of that; cells claim primitives by
 // their inflated boxes.  A primitive two cells share is tested twice at worst (same t, same index: the any-order rule keeps one).
 // e_rel: rectangle growth relative to |o| + cbound -- RTMI_F32's float sphere test calls a hit up to 3.1e-3 (|o| + cbound) outside the sphere
@@ -1101,8 +1105,11 @@ __device__ inline void bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, fl
         const float e = (omax + sc.bvh_cbound) * e_rel;
         const float p0x = fmaf(tn, dx, ox), p1x = fmaf(tf, dx, ox), p0z = fmaf(tn, dz, oz), p1z = fmaf(tf, dz, oz);
         const float gmax = (float)(G - 1);
-        const float fx0 = (fminf(p0x, p1x) - e - sc.grid_lo_x) * sc.grid_inv_x, fx1 = (fmaxf(p0x, p1x) + e - sc.grid_lo_x) * sc.grid_inv_x;
-        const float fz0 = (fminf(p0z, p1z) - e - sc.grid_lo_z) * sc.grid_inv_z, fz1 = (fmaxf(p0z, p1z) + e - sc.grid_lo_z) * sc.grid_inv_z;
+        // cell coordinate = (p - lo) * inv as one fma (p * inv + (-lo * inv)); its rounding (a few 2^-24 of a coordinate <= grid_n) is far below
+        // the margin e * inv, which is at least 2^-16 (|o| + cbound) * inv >= 2^-16 of the layer's extent in cells
+        const float ax = sc.grid_inv_x, az = sc.grid_inv_z, bx = -sc.grid_lo_x * ax, bz = -sc.grid_lo_z * az, ex = e * ax, ez = e * az;
+        const float fx0 = fmaf(fminf(p0x, p1x), ax, bx) - ex, fx1 = fmaf(fmaxf(p0x, p1x), ax, bx) + ex;
+        const float fz0 = fmaf(fminf(p0z, p1z), az, bz) - ez, fz1 = fmaf(fmaxf(p0z, p1z), az, bz) + ez;
         const int i0 = (int)fminf(fmaxf(floorf(fx0), 0.0f), gmax), i1 = (int)fminf(fmaxf(floorf(fx1), 0.0f), gmax);
         const int j0 = (int)fminf(fmaxf(floorf(fz0), 0.0f), gmax), j1 = (int)fminf(fmaxf(floorf(fz1), 0.0f), gmax);
         const int wi = i1 - i0, wj = j1 - j0;
@@ -1110,9 +1117,13 @@ __device__ inline void bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, fl
         const int *cells = sc.grid_cells;
         const int a00 = cells[j0 * G + i0], a10 = cells[j0 * G + i1], a01 = cells[j1 * G + i0], a11 = cells[j1 * G + i1]; // four loads in flight (duplicates when the rectangle is narrower)
         // the cell the segment starts in goes first (its hits prune the others)
-        const int ni = ((int)fminf(fmaxf(floorf((p0x - sc.grid_lo_x) * sc.grid_inv_x), (float)i0), (float)i1)) - i0;
-        const int nj = ((int)fminf(fmaxf(floorf((p0z - sc.grid_lo_z) * sc.grid_inv_z), (float)j0), (float)j1)) - j0;
+#if RTMI_GRID_NEAR
+        const int ni = ((int)fminf(fmaxf(floorf(fmaf(p0x, ax, bx)), (float)i0), (float)i1)) - i0;
+        const int nj = ((int)fminf(fmaxf(floorf(fmaf(p0z, az, bz)), (float)j0), (float)j1)) - j0;
         const int k = ni + 2 * nj;
+#else
+        const int k = 0;
+#endif
         near = k == 0 ? a00 : (k == 1 ? a10 : (k == 2 ? a01 : a11));
         c0 = k == 0 ? RTMI_BVH_EMPTY : a00;
         c1 = (wi == 0 || k == 1) ? RTMI_BVH_EMPTY : a10;
@@ -1369,19 +1380,20 @@ __device__ inline void ext_medium_test(SceneRef sc, int idx, Path<double> &P, do
 }
 
 // the flat scan (FP32 cull + exact test) over all primitives
-__device__ inline void scan_all_cull_ext(SceneRef sc, const Path<double> &P, double a, double tmin, ExtHit &H) {
-    const int n = sc.n_all;
+// [lo, hi): only the primitives of this index range (RTMI_MEDIA_HITLIST scans the list in pieces, between its media); default: all
+__device__ inline void scan_all_cull_ext(SceneRef sc, const Path<double> &P, double a, double tmin, ExtHit &H, int lo = 0, int hi = 0x7fffffff) {
+    const int n = min(sc.n_all, hi);
     if (n <= 0) return;
     const int last = n - 1;
     const CullRay c = make_cull_ray(P, a, sc.cull_t_lo, sc.cull_t_hi);
-    for (int g = 0; g < n; g += 4) {
+    for (int g = lo & ~3; g < n; g += 4) {
         const CullGroup G = load_cull_group(sc.cull20, g >> 2);
         const float d0 = cull_disc(G, 0, c), d1 = cull_disc(G, 1, c), d2 = cull_disc(G, 2, c), d3 = cull_disc(G, 3, c);
         if (fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)) >= 0.0f) {
-            if (d0 >= 0.0f) ext_prim_test<true>(sc, g, P, tmin, H);
-            if (d1 >= 0.0f && g + 1 <= last) ext_prim_test<true>(sc, g + 1, P, tmin, H);
-            if (d2 >= 0.0f && g + 2 <= last) ext_prim_test<true>(sc, g + 2, P, tmin, H);
-            if (d3 >= 0.0f && g + 3 <= last) ext_prim_test<true>(sc, g + 3, P, tmin, H);
+            if (d0 >= 0.0f && g >= lo) ext_prim_test<true>(sc, g, P, tmin, H);
+            if (d1 >= 0.0f && g + 1 <= last && g + 1 >= lo) ext_prim_test<true>(sc, g + 1, P, tmin, H);
+            if (d2 >= 0.0f && g + 2 <= last && g + 2 >= lo) ext_prim_test<true>(sc, g + 2, P, tmin, H);
+            if (d3 >= 0.0f && g + 3 <= last && g + 3 >= lo) ext_prim_test<true>(sc, g + 3, P, tmin, H);
         }
     }
 }
@@ -1393,7 +1405,7 @@ __device__ inline float ext_best_hi(const ExtHit &H) { return (H.t < 3.0e38 ? fl
 #define RTMI_BVH_SUSPEND_WORDS_EXT 7 // node, tos, top, H.t (2 words), H.F, H.W   (H.any <=> H.F != 0x7fffffff)
 template <bool SLICE = false, bool COUNT = false>
 __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, ExtHit &H, int *susp = nullptr, bool resume = false,
-                                    int min_lanes = 0, unsigned *cnt = nullptr) {
+                                    int min_lanes = 0, unsigned *cnt = nullptr, int lo = 0, int hi = 0x7fffffff) {
     const BvhRay r = make_bvh_ray(sc, P, a, tmin);
     const int stride = blockDim.x;
     int *sw = susp + threadIdx.x;
@@ -1404,12 +1416,12 @@ __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> 
         H.t = __hiloint2double(sw[4 * stride], sw[3 * stride]);
         H.F = sw[5 * stride]; H.W = sw[6 * stride]; H.any = H.F != 0x7fffffff;
     } else {
-        if (!r.ok) { if (COUNT) cnt[1] += (unsigned)sc.n_all; scan_all_cull_ext(sc, P, a, tmin, H); return true; }
+        if (!r.ok) { if (COUNT) cnt[1] += (unsigned)sc.n_all; scan_all_cull_ext(sc, P, a, tmin, H, lo, hi); return true; }
         if (COUNT) cnt[1] += (unsigned)sc.n_big;
-        for (int k = 0; k < sc.n_big; ++k) ext_prim_test<true>(sc, sc.big_idx[k], P, tmin, H);
+        for (int k = 0; k < sc.n_big; ++k) if (sc.big_idx[k] >= lo && sc.big_idx[k] < hi) ext_prim_test<true>(sc, sc.big_idx[k], P, tmin, H);
         cur = bvh_cursor_at_root(sc, stack);
     }
-    auto leaf = [&](int code) { ext_prim_test<false>(sc, (~code) & 0x3fffffff, P, tmin, H); };
+    auto leaf = [&](int code) { const int idx = (~code) & 0x3fffffff; if (idx >= lo && idx < hi) ext_prim_test<false>(sc, idx, P, tmin, H); };
     auto best = [&]() { return ext_best_hi(H); };
     bvh_traverse<COUNT, SLICE>(sc, r, cur, min_lanes, leaf, best, cnt);
     if (SLICE && cur.node != RTMI_BVH_EMPTY) { // suspended
@@ -1421,7 +1433,7 @@ __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> 
     }
     if (!r.time_ok) { // e.g. after Isotropic.scatter, which sets the ray's time to the hit's t (shader.clj:136)
         if (COUNT) cnt[1] += (unsigned)sc.n_moving_all;
-        for (int k = 0; k < sc.n_moving_all; ++k) ext_prim_test<true>(sc, sc.moving_all[k], P, tmin, H);
+        for (int k = 0; k < sc.n_moving_all; ++k) if (sc.moving_all[k] >= lo && sc.moving_all[k] < hi) ext_prim_test<true>(sc, sc.moving_all[k], P, tmin, H);
     }
     return true;
 }

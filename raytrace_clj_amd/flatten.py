@@ -57,6 +57,7 @@ class FlatScene:
         self.images = []            # [h, w, 3] uint8 arrays; TEX_IMAGE's first parameter indexes this list
         # ConstantMedium: the primitive indices of the media in the order (and multiplicity) the reference's descent calls their hit?
         self.media_calls = np.zeros(0, np.int32)
+        self.media_mode = 0  # RTMI_MEDIA_DESCENT (bvh-node descent, un-narrowed t-max) | 1 = RTMI_MEDIA_HITLIST (the world is a Hitlist)
 
     n_world = None  # primitives [0, n_world) are the world; the rest are medium boundaries (None: all of them are the world)
 
@@ -68,18 +69,22 @@ class FlatScene:
 _LEAF_TYPES = (hit.Sphere, hit.UVSphere, hit.MovingSphere, hit.RectXY, hit.RectXZ, hit.RectYZ, hit.Triangle)
 
 
-def _leaves(world, out, seen, chain=(), flip=0, in_list=False, calls=None):
+def _leaves(world, out, seen, chain=(), flip=0, in_list=False, calls=None, under_bvh=False, modes=None):
     """out gets (leaf, chain, flip): chain = the Translate/RotateY wrappers around the leaf, outermost first.
     calls (optional list) gets the key of every ConstantMedium in the order, and as often as, the reference's descent calls
     its hit?: make-bvh stores a lone item as bvh-node(L, L) (hitable.clj:113-114) and bvh-node.hit? evaluates both children
-    (hitable.clj:101-102), so such a subtree is visited twice per ray -- harmless for surfaces, two random draws for a medium."""
+    (hitable.clj:101-102), so such a subtree is visited twice per ray -- harmless for surfaces, two random draws for a medium.
+    modes (optional set) collects how the media are reached: "descent" (only bvh-nodes / wrappers above: un-narrowed t-max,
+    hitable.clj:99-105) or "hitlist" (only Hitlists / wrappers above: the t-max narrowed by the items before it, hitable.clj:15-26)."""
     if isinstance(world, hit.Hitlist):
         for it in world.items:
-            _leaves(it, out, seen, chain, flip, True, calls)
+            _leaves(it, out, seen, chain, flip, True, calls, under_bvh, modes)
     elif isinstance(world, hit.ConstantMedium):
-        if in_list:
-            raise UnsupportedOnGpuPath("ConstantMedium inside a Hitlist (t-max narrowing between siblings) is not supported on the GPU "
-                                       "path: build the world with make-bvh, like every scene of scene.clj")
+        if in_list and under_bvh:
+            raise UnsupportedOnGpuPath("a ConstantMedium inside a Hitlist that sits below a bvh-node is not supported on the GPU path (its t-max is "
+                                       "narrowed by some siblings and not by others): make the world one Hitlist, or one make-bvh tree")
+        if modes is not None:
+            modes.add("hitlist" if in_list else "descent")
         key = (id(world), chain, flip)
         if calls is not None:
             calls.append(key)
@@ -87,16 +92,16 @@ def _leaves(world, out, seen, chain=(), flip=0, in_list=False, calls=None):
             seen.add(key)
             out.append((world, chain, flip))
     elif isinstance(world, hit.bvh_node):
-        _leaves(world.left, out, seen, chain, flip, in_list, calls)
-        _leaves(world.right, out, seen, chain, flip, in_list, calls)
+        _leaves(world.left, out, seen, chain, flip, in_list, calls, True, modes)
+        _leaves(world.right, out, seen, chain, flip, in_list, calls, True, modes)
     elif isinstance(world, hit.Box):
-        _leaves(world.sides, out, seen, chain, flip, False, calls)  # a Box is opaque to its surroundings: its inner Hitlist narrows only its own sides
+        _leaves(world.sides, out, seen, chain, flip, in_list, calls, under_bvh, modes)  # (hit? sides ...) with the caller's interval: its six rectangles splice into the enclosing list
     elif isinstance(world, hit.FlipNormals):
-        _leaves(world.item, out, seen, chain, flip ^ 1, in_list, calls)
+        _leaves(world.item, out, seen, chain, flip ^ 1, in_list, calls, under_bvh, modes)
     elif isinstance(world, hit.Translate):
-        _leaves(world.item, out, seen, chain + ((XFORM_TRANSLATE, tuple(float(v) for v in world.offset)),), flip, in_list, calls)
+        _leaves(world.item, out, seen, chain + ((XFORM_TRANSLATE, tuple(float(v) for v in world.offset)),), flip, in_list, calls, under_bvh, modes)
     elif isinstance(world, hit.RotateY):
-        _leaves(world.obj, out, seen, chain + ((XFORM_ROTATE_Y, (float(world.sin_theta), float(world.cos_theta), 0.0)),), flip, in_list, calls)
+        _leaves(world.obj, out, seen, chain + ((XFORM_ROTATE_Y, (float(world.sin_theta), float(world.cos_theta), 0.0)),), flip, in_list, calls, under_bvh, modes)
     elif isinstance(world, _LEAF_TYPES):
         key = (id(world), chain, flip)  # the same record under two different instances is two primitives
         if key not in seen:
@@ -104,7 +109,7 @@ def _leaves(world, out, seen, chain=(), flip=0, in_list=False, calls=None):
             out.append((world, chain, flip))
     elif isinstance(world, (list, tuple)):
         for it in world:
-            _leaves(it, out, seen, chain, flip, True, calls)
+            _leaves(it, out, seen, chain, flip, True, calls, under_bvh, modes)
     else:
         raise UnsupportedOnGpuPath("%s is not supported on the GPU path" % type(world).__name__)
 
@@ -129,8 +134,12 @@ def flatten(scene_or_world, camera=None, perlin_seed=None):
         world, camera = scene_or_world["world"], scene_or_world["camera"]
     else:
         world = scene_or_world
-    leaves, medium_calls = [], []
-    _leaves(world, leaves, set(), calls=medium_calls)
+    leaves, medium_calls, modes = [], [], set()
+    _leaves(world, leaves, set(), calls=medium_calls, modes=modes)
+    if len(modes) > 1:
+        raise UnsupportedOnGpuPath("the world reaches some ConstantMedium records through a Hitlist and others through bvh-nodes only: not supported on the GPU path")
+    if modes == {"hitlist"} and len(set(medium_calls)) != len(medium_calls):
+        raise UnsupportedOnGpuPath("the same ConstantMedium record listed twice in a Hitlist is not supported on the GPU path")
 
     textures, materials = _Interner(), _Interner()
     uses, images = {"perlin": False}, []
@@ -195,6 +204,7 @@ def flatten(scene_or_world, camera=None, perlin_seed=None):
     fs.n_world = n_world
     index_of = {(id(o), chain, flip): i for i, (o, chain, flip) in enumerate(leaves[:n_world])}
     fs.media_calls = np.array([index_of[k] for k in medium_calls], np.int32)
+    fs.media_mode = 1 if modes == {"hitlist"} else 0  # RTMI_MEDIA_HITLIST: the list's t-max narrowing reaches the media (rtmi_scene_set_media_mode)
     n = len(leaves)
     fs.prim_kind = np.zeros(n, np.int32)
     fs.prim_geom = np.zeros((n, PRIM_STRIDE), np.float64)

@@ -245,7 +245,7 @@ def test_gpu_clj_calls_conform_to_the_header():
     assert n >= 10
     called = {f[2].strip('"') for top in forms for f in walk(top) if is_list(f, "call-int")}
     # the one-GPU path and the multi-GPU path must both create the scene WITH its Perlin tables, ImageMap pixels and media calls
-    for need in ("rtmi_init", "rtmi_scene_create_ex", "rtmi_scene_set_perlin", "rtmi_scene_set_images", "rtmi_scene_set_media_calls", "rtmi_render",
+    for need in ("rtmi_init", "rtmi_scene_create_ex", "rtmi_scene_set_perlin", "rtmi_scene_set_images", "rtmi_scene_set_media_calls", "rtmi_scene_set_media_mode", "rtmi_render",
                  "rtmi_scene_clone", "rtmi_render_multi", "rtmi_scene_destroy", "rtmi_shutdown"):
         assert need in called, need
     by_name = {f[2]: f for f in forms if isinstance(f, list) and len(f) > 2 and f[1] in ("defn", "defn-")}
@@ -253,7 +253,7 @@ def test_gpu_clj_calls_conform_to_the_header():
         uses = {x[1] for x in walk(by_name[entry]) if is_list(x)}
         assert "create-scene!" in uses, "%s must build its scene through create-scene! (images, Perlin tables, media calls)" % entry
     helper = {f[2].strip('"') for f in walk(by_name["create-scene!"]) if is_list(f, "call-int")}
-    assert helper == {"rtmi_scene_create_ex", "rtmi_scene_set_perlin", "rtmi_scene_set_images", "rtmi_scene_set_media_calls"}
+    assert helper == {"rtmi_scene_create_ex", "rtmi_scene_set_perlin", "rtmi_scene_set_images", "rtmi_scene_set_media_calls", "rtmi_scene_set_media_mode"}
 
 
 def test_integration_md_snippets_conform_to_the_header():

@@ -361,3 +361,71 @@ def test_entry_grid_is_bit_identical_to_the_flat_scan(monkeypatch):
             visits[spec] = ctx.last_traversal_counters()[0] / 2 / float(out[2][0])
             ds.close(); ctx.close()
         assert visits["1:4"] < 0.8 * visits["0:4"], (name, visits)
+
+
+# ---- ConstantMedium inside a Hitlist (hitable.clj:15-26 + 516-541) -------------------------------------------------------------------------------------
+def hitlist_media_scene(seed=5):
+    """a world that IS a Hitlist (no make-bvh): surfaces, a fog ball in the middle of the list, more surfaces -- some of them inside and behind
+    the fog --, a second medium bounded by a Box, nested Hitlists and a translated, rotated box"""
+    from raytrace_clj_amd.util import vec3
+    rng = np.random.default_rng(seed)
+    H, S, T = r.hitable, r.shader, r.texture
+    grey = S.lambertian(albedo=T.constant(color=vec3(0.6, 0.6, 0.6)))
+    items = [H.sphere(center=vec3(0, 0, 0), radius=500, material=S.diffuse_light(tex=T.constant(color=vec3(0.8, 0.9, 1.0)))),
+             H.sphere(center=vec3(0, -1000, 0), radius=1000, material=S.lambertian(albedo=T.checkerboard(tex0=T.constant(color=vec3(0.2, 0.3, 0.1)), tex1=T.constant(color=vec3(0.9, 0.9, 0.9)), scale=10)))]
+    def ball():
+        return H.sphere(center=vec3(rng.uniform(-5, 5), rng.uniform(0.2, 2.5), rng.uniform(-5, 5)), radius=float(rng.uniform(0.2, 0.7)),
+                        material=[grey, S.metal(albedo=T.constant(color=vec3(0.8, 0.7, 0.6)), fuzz=0.1), S.dielectric(ri=1.5)][int(rng.integers(0, 3))])
+    items += [ball() for _ in range(12)]
+    fog = H.constant_medium(boundary=H.sphere(center=vec3(0, 1.5, 0), radius=2.5, material=S.dielectric(ri=1.5)), density=0.35, albedo=T.constant(color=vec3(0.9, 0.9, 0.9)))
+    items.append(fog)                                                         # narrowed by everything above, narrows everything below
+    items.append(H.hitlist(items=[ball() for _ in range(6)]))                 # a nested Hitlist splices in
+    items.append(H.translate(item=H.rotate_y(item=H.box(p0=vec3(0, 0, 0), p1=vec3(1, 2, 1), material=grey), theta=25.0), offset=vec3(1.5, 0, -2.0)))
+    smoke = H.constant_medium(boundary=H.box(p0=vec3(-4, 0, 1), p1=vec3(-1, 2, 4), material=grey), density=0.8, albedo=T.constant(color=vec3(0.1, 0.1, 0.1)))
+    items.append(smoke)
+    items += [ball() for _ in range(8)]
+    cam = r.camera.thin_lens_camera(lookfrom=vec3(9, 3, 7), lookat=vec3(0, 1, 0), vup=vec3(0, 1, 0), vfov=40, aspect=2.0, aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0)
+    return {"camera": cam, "world": H.hitlist(items=items)}
+
+
+def test_media_inside_a_hitlist_match_the_nested_oracle(oracle):
+    """A world built as a Hitlist with ConstantMedium items: Hitlist.hit? hands every item the t-max narrowed by the items before it, and a
+    medium draws its random number inside hit?, so WHERE in the list it stands changes what it draws (round 2 rejected such worlds).  The
+    device scans the list in pieces around its media (RTMI_MEDIA_HITLIST); the oracle evaluates the nested records the way the reference does
+    (oracle/tree.py, node_hit).  Geometry logs equal (media hits within the log tolerance: ocml vs glibc log), images within the tolerance,
+    BVH and flat scan alike -- and the narrowing must matter: declared as a bvh-descent world the same primitives give a different frame."""
+    from oracle.tree import flatten_with_tree
+    sc = hitlist_media_scene()
+    f = flatten_with_tree(sc)
+    assert f.media_mode == 1 and len(f.media_calls) == 2 and list(f.media_calls) == sorted(f.media_calls)
+    nx, ny, ns = 64, 32, 8
+    exp_lin, exp_q, exp_cnt = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, nthreads=16)
+    rng = np.random.default_rng(2)
+    n = 4096
+    keys = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+    cam = oracle.probe_camera(f, rng.random((n, 2)), keys)
+    ctr0 = int(cam[:, 7].max())
+    ergb, enseg, elog, enlog = oracle.probe_paths(f, cam[:, :7], keys, depth=50, ctr0=ctr0, max_seg=6)
+    media = set(int(m) for m in f.media_calls)
+    logged = np.arange(6)[None, :] < enlog[:, None]
+    assert np.isin(elog[:, :, 0][logged].astype(int), list(media)).sum() > 50, "the probe paths must scatter inside the media"
+    ctx = core.Context(0)
+    ds = core.DeviceScene(f, ctx=ctx)
+    frames = {}
+    for accel in (1, 0):
+        ctx.set_option("accel", accel)
+        rgb, nseg, log, nlog = ds.probe_paths(cam[:, :7], keys, depth=50, ctr0=ctr0, max_seg=6)
+        same = nseg == enseg
+        assert same.mean() > 0.995, accel
+        assert np.array_equal(log[same][:, :, 0], elog[same][:, :, 0]) and np.allclose(log[same], elog[same], rtol=1e-9, atol=1e-9), accel
+        assert np.allclose(rgb[same], ergb[same], atol=1e-9, rtol=0)
+        lin, q, cnt = ds.render(nx, ny, ns)
+        assert abs(int(cnt[0]) - int(exp_cnt[0])) <= 52 + 1e-5 * int(exp_cnt[0]) and rms(lin, exp_lin) <= RMS_TOL, (accel, rms(lin, exp_lin), cnt, exp_cnt)
+        frames[accel] = (lin, cnt)
+    assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][1], frames[1][1]), "BVH and flat scan: the same frame"
+    core.check(r._ffi.lib().rtmi_scene_set_media_mode(ds.handle, 0))  # the same primitives read as a make-bvh world: un-narrowed media
+    other, _, ocnt = ds.render(nx, ny, ns)
+    assert not np.array_equal(other, frames[1][0]) and int(ocnt[0]) != int(frames[1][1][0]), "the narrowing must matter in this scene"
+    with pytest.raises(core.RtmiError):
+        core.check(r._ffi.lib().rtmi_scene_set_media_mode(ds.handle, 7))
+    ds.close(); ctx.close()

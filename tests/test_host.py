@@ -115,6 +115,26 @@ def test_flatten_rejects_unknown_records():
 
 
 # ---- golden fixtures: the oracle reproduces them (so a changed oracle cannot silently move the goalposts) ------------
+def test_flatten_media_modes():
+    """where a ConstantMedium stands decides the t-max its hit? is handed: below bvh-nodes only -> RTMI_MEDIA_DESCENT (un-narrowed,
+    hitable.clj:99-105), inside Hitlists only -> RTMI_MEDIA_HITLIST (narrowed by the items before it, hitable.clj:15-26: list order kept,
+    nested Hitlists and Boxes spliced in), both at once -> unsupported"""
+    H, S, T = r.hitable, r.shader, r.texture
+    grey = S.lambertian(albedo=T.constant(color=vec3(0.5, 0.5, 0.5)))
+    a, b, c = (H.sphere(center=vec3(k, 0, 0), radius=0.4, material=grey) for k in range(3))
+    fog = H.constant_medium(boundary=H.sphere(center=vec3(1, 0, 0), radius=2.0, material=grey), density=0.5, albedo=T.constant(color=vec3(1, 1, 1)))
+    cam = r.camera.pinhole_camera(lookfrom=vec3(0, 0, 5), lookat=vec3(0, 0, 0), vup=vec3(0, 1, 0), vfov=40.0, aspect=1.0)
+    from raytrace_clj_amd import flatten
+    f = flatten.flatten({"camera": cam, "world": H.hitlist(items=[a, H.hitlist(items=[b, fog]), c])})
+    assert f.media_mode == 1 and list(f.media_calls) == [2] and f.n_prims == 4 and list(f.prim_kind[:4] & 15) == [0, 0, 7, 0]
+    f = flatten.flatten({"camera": cam, "world": H.make_bvh([a, b, fog, c], 0.0, 1.0)})
+    assert f.media_mode == 0 and len(f.media_calls) >= 1
+    with pytest.raises(flatten.UnsupportedOnGpuPath):
+        flatten.flatten({"camera": cam, "world": H.bvh_node(a, H.hitlist(items=[b, fog]), a.bbox(0.0, 1.0))})  # (the reference's Hitlist has no bbox: built by hand)
+    with pytest.raises(flatten.UnsupportedOnGpuPath):
+        flatten.flatten({"camera": cam, "world": H.hitlist(items=[a, fog, b, fog])})
+
+
 def test_golden_rng():
     cases = json.load(open(os.path.join(GOLD, "rng.json")))["cases"]
     from oracle.oracle import Oracle

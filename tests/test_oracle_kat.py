@@ -493,9 +493,35 @@ def test_medium_semantics(oracle):
     rgb, nseg, log, nlog = oracle.probe_paths(ft2, rays, np.arange(20000) + 5, depth=50, max_seg=1)
     frac = (log[:, 0, 0] == m).mean()
     assert abs(frac - (1 - np.exp(-1.4))) < 0.01
-    # a medium under a Hitlist is rejected (t-max narrowing between siblings is not reproduced on the device)
-    with pytest.raises(r.UnsupportedOnGpuPath):
-        fl.flatten(H.hitlist(items=[light, H.constant_medium(boundary=ball, density=1.0, albedo=T.constant(color=vec3(1, 1, 1)))]), None)
+    # a medium under a Hitlist: its t-max comes narrowed by the items before it -- flagged for the device (RTMI_MEDIA_HITLIST, round 3) ...
+    fh = fl.flatten(H.hitlist(items=[light, H.constant_medium(boundary=ball, density=1.0, albedo=T.constant(color=vec3(1, 1, 1)))]), None)
+    assert fh.media_mode == 1 and list(fh.media_calls) == [1]
+    # ... and the nested oracle narrows it: a wall at t = 3, listed BEFORE a thick fog whose ball spans t in [2, 6] on this ray, clips the fog's
+    # segment to [2, 3]; listed AFTER the fog it does not (hitable.clj:15-26 hands every item the closest hit SO FAR)
+    from oracle.tree import flatten_with_tree
+    wall = H.rect_xy(x0=-5, y0=-5, x1=5, y1=5, k=-3.0, material=S.lambertian(albedo=T.constant(color=vec3(0.5, 0.5, 0.5))))
+    fogball = H.sphere(center=vec3(0, 0, -4), radius=2.0, material=S.dielectric(ri=1.5))
+    def listed(items):
+        cam = r.camera.pinhole_camera(lookfrom=vec3(0, 0, 0), lookat=vec3(0, 0, -1), vup=vec3(0, 1, 0), vfov=40.0, aspect=1.0)
+        return flatten_with_tree({"camera": cam, "world": H.hitlist(items=items)})
+    thin = 0.05  # the free path (mean 20) mostly exceeds a 1-long segment and mostly not a 4-long one... the draws are the same in both scenes
+    n = 4000
+    rays = np.tile(ray7(vec3(0, 0, 0), vec3(0, 0, -1)), (n, 1))
+    keys = np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    hits = {}
+    for name, items in (("wall first", [wall, H.constant_medium(boundary=fogball, density=thin * 10, albedo=T.constant(color=vec3(1, 1, 1)))]),
+                        ("fog first", [H.constant_medium(boundary=fogball, density=thin * 10, albedo=T.constant(color=vec3(1, 1, 1))), wall])):
+        ft = listed(items)
+        mi = int(np.flatnonzero((ft.prim_kind[:ft.n_prims] & 15) == 7)[0])
+        rgb, nseg, log, nlog = oracle.probe_paths(ft, rays, keys, depth=1, ctr0=0, max_seg=1)
+        t = log[:, 0, 1]
+        hits[name] = (log[:, 0, 0] == mi, t)
+        assert t.max() <= 3.0 + 1e-12, name  # nothing is ever reported behind the wall
+    (in_a, t_a), (in_b, t_b) = hits["wall first"], hits["fog first"]
+    # the same draw scatters inside the fog in both scenes iff its free path fits the CLIPPED segment [2, 3]; with the fog listed first the
+    # un-clipped segment [2, 6] accepts more draws, but those beyond t = 3 lose to the wall listed after it
+    assert abs(in_a.mean() - (1 - np.exp(-0.5 * 1.0))) < 0.03 and np.all(t_a[in_a] <= 3.0) and np.all(t_a[in_a] >= 2.0)
+    assert np.array_equal(in_a, in_b) and np.allclose(t_a, t_b), "for this geometry both orders agree hit for hit (the wall clips either way)"
 
 
 def test_media_scenes_render(oracle):
