@@ -612,6 +612,13 @@ def test_bench_json_schema():
     assert rf["launch_ms"] * rf["launches_per_step"] <= d["ms_per_step"] * 1.02, "a kernel cannot take longer than the step it is in"
     assert d["aabb_tests_per_segment"] > 2 and d["prim_tests_per_segment"] >= 2
     assert d["pipelined"]["value"] > 100 and d["c2"]["value"] > 100 and d["c4"]["value"] > 100 and d["c2"]["workload"].startswith("C2: 800x400x64spp")
+    assert d["c5"]["value"] > 100 and d["c5"]["workload"].startswith("C5: 1920x1080x4096spp") and d["c5"]["segments_per_sample"] > 2.8  # the divergence-stress configuration
+    if rf["frac"] is not None:  # a PMC profile of this workload is committed: the calibrated issue model and the lane occupancy come with it
+        im = rf["issue_model"]
+        assert 0 < im["frac_low"] <= rf["frac"] <= im["frac_high"] <= 1 and set(im["per_class_price_cycles"]) >= {"FMA_F64", "INT32", "OTHER"}
+        assert 0.3 < rf["lanes_active"] <= 1 and rf["counts"]["stale"] in (True, False)
+        for k in ("c2", "c4", "c5"):
+            assert d[k]["roofline"]["frac"] is None or 0 < d[k]["roofline"]["frac"] <= 1
 
 
 def test_bench_other_configs_and_flat():
@@ -641,6 +648,7 @@ def test_bench_gpus_n_in_one_process():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["launch_form"].startswith("one host process")
     assert d.get("rehearsal", False) == (torch.cuda.device_count() < 2)
     assert abs(d["config"]["segments_per_sample"] - 2.5) < 0.6 and d["gather_ms"] >= 0
+    assert d["gather_path"] == ("same-device" if torch.cuda.device_count() < 2 else "rccl")  # on distinct devices bench.py forces RCCL: never silent peer copies
 
 
 def test_frame_pipeline_renders_the_same_frames():

@@ -255,8 +255,9 @@ def test_config_c3_full_size(oracle):
 
 
 def test_config_c5_full_size(oracle):
-    """BASELINE configs[4]: 1920x1080x4096spp, dielectric-heavy cover scene (80 % glass), 24 sample passes: determinism,
-    counters in range (long specular chains), one oracle spot region at the full 4096 spp that is also the crop of the frame."""
+    """BASELINE configs[4]: 1920x1080x4096spp, dielectric-heavy cover scene (80 % glass), 3 sample passes through the default
+    64 GiB sample buffer (the many-pass form, 24+ passes through 8 GiB, is tests/test_gpu_round3.py::test_config_c5_many_passes):
+    determinism, counters in range (long specular chains), one oracle spot region at the full 4096 spp that is also the crop of the frame."""
     nx, ny, ns = 1920, 1080, 4096
     sc = r.scene.make_random_scene(nx, ny, 11, False, mix=(0.1, 0.2))
     f = fl.flatten(sc)
