@@ -96,7 +96,7 @@ int rtmi_version(void);
 int rtmi_init(int device, uint32_t flags, rtmi_ctx **out_ctx);
 int rtmi_shutdown(rtmi_ctx *ctx);
 /* knobs: "accel" (RTMI_ACCEL_*; default RTMI_ACCEL_BVH -- bit-identical to the flat scan), "count_traversal" (0/1: the next
- * renders run the counting instantiation of the BVH kernel, see rtmi_last_traversal_counters), "suspend_lanes" (0..64, default 8: the
+ * renders run the counting instantiation of the BVH kernel, see rtmi_last_traversal_counters), "suspend_lanes" (0..64, default 12: the
  * BVH traversal of a wave stops descending / hands the wave back when fewer lanes than this are still descending / in the tree, and the
  * parked lanes resume in the next trip; 0 = the plain loop; the image does not depend on it), "workspace_bytes" (sample-buffer budget, default 64 GiB, allocated as needed: a frame is rendered in as many sample passes as
  * it takes), "blocks_per_cu" (cap on resident trace workgroups per CU; the launch never exceeds what stays resident),
