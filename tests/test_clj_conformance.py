@@ -285,3 +285,66 @@ def test_reader_rejects_what_it_should():
             check_calls(read_forms(src), protos, flat_map, True, "synthetic")
     good = '(defn g [ctx f] (let [scn (PointerByReference.)] (call-int "rtmi_scene_create" ctx (int 1) (:prim-kind f) (:cam f) (:prim-kind f) (int 1) (:prim-kind f) (:prim-kind f) (:cam f) (int 1) (:prim-kind f) (:cam f) (:prim-kind f) (int (:cam-kind f)) (:cam f) scn)))'
     assert check_calls(read_forms(good), protos, flat_map, True, "synthetic") == 1
+
+
+# ---- the flattener reads the reference's records by field keyword: every (:field record) must name a field the record has ------------------------------
+# the reference's record declarations (defrecord Name [fields]) -- hitable.clj:15,36,97,141,180,224,269,301,333,375,391,410,491,516,548;
+# shader.clj:29,46,76,114,129; texture.clj:14,26,44,60,74,88,103,113,126; camera.clj:8,35 -- as data
+REFERENCE_RECORDS = {
+    "Hitlist": ["items"], "bvh_node": ["left", "right", "box"], "UVSphere": ["center", "radius", "material"], "Sphere": ["center", "radius", "material"],
+    "MovingSphere": ["center0", "t0", "center1", "t1", "radius", "material"], "RectXY": ["x0", "y0", "x1", "y1", "k", "material"],
+    "RectXZ": ["x0", "z0", "x1", "z1", "k", "material"], "RectYZ": ["y0", "z0", "y1", "z1", "k", "material"], "FlipNormals": ["item"],
+    "Translate": ["item", "offset"], "RotateY": ["obj", "rotated-bbox", "sin-theta", "cos-theta"], "Box": ["p0", "p1", "sides"],
+    "ConstantMedium": ["boundary", "density", "phase-fn"], "Triangle": ["v0", "v1", "v2", "material"],
+    "Lambertian": ["albedo"], "Metal": ["albedo", "fuzz"], "Dielectric": ["ri"], "DiffuseLight": ["tex"], "Isotropic": ["albedo"],
+    "Constant": ["color"], "UVGradient": ["co", "cu", "cv", "cuv"], "Checkerboard": ["tex0", "tex1", "scale"], "PerlinNoise": ["scale"],
+    "PerlinTurbulence": ["scale", "depth"], "Marble": ["scale", "depth"], "FlipTextureU": ["tex"], "FlipTextureV": ["tex"], "ImageMap": ["image"],
+    "PinholeCamera": ["origin", "lleft", "horiz", "vert"], "ThinLensCamera": ["origin", "lleft", "horiz", "vert", "u", "v", "w", "aperture", "t0", "t1"],
+}
+
+
+def _field_reads(form, subject):
+    """keywords read off `subject` inside form: (:kw subject)"""
+    return [f[1][1:] for f in walk(form) if is_list(f) and len(f) == 3 and isinstance(f[1], str) and f[1].startswith(":") and f[2] == subject]
+
+
+def test_gpu_clj_reads_only_fields_the_reference_records_have():
+    forms = read_forms(open(GPU_CLJ).read())
+    checked = 0
+    seen_types = set()
+    for top in forms:
+        for f in walk(top):
+            if is_list(f, "extend-protocol"):  # TypeName (method [this ...] body) ...
+                items, k = f[3:], 0
+                while k < len(items):
+                    t = items[k]
+                    k += 1
+                    while k < len(items) and isinstance(items[k], list):
+                        impl = items[k]
+                        k += 1
+                        if t == "Object":
+                            continue
+                        assert t in REFERENCE_RECORDS, "gpu.clj extends a record the reference does not declare: %s" % t
+                        seen_types.add(t)
+                        this = impl[2][1]  # first parameter of (leaves [this c f l b] ...)
+                        for kw in _field_reads(impl, this):
+                            assert kw in REFERENCE_RECORDS[t], "(:%s %s) -- %s has fields %s" % (kw, t, t, REFERENCE_RECORDS[t])
+                            checked += 1
+            if is_list(f, "condp") and len(f) > 4 and f[2] == "instance?":  # (condp instance? x Type expr Type expr ... [default])
+                subject, clauses = f[3], f[4:]
+                for j in range(0, len(clauses) - 1, 2):
+                    t, expr = clauses[j], clauses[j + 1]
+                    if not isinstance(t, str):
+                        continue
+                    assert t in REFERENCE_RECORDS, "gpu.clj dispatches on a record the reference does not declare: %s" % t
+                    seen_types.add(t)
+                    for kw in _field_reads(expr, subject):
+                        assert kw in REFERENCE_RECORDS[t], "(:%s %s) -- %s has fields %s" % (kw, t, t, REFERENCE_RECORDS[t])
+                        checked += 1
+    assert checked >= 60, checked
+    # every record the GPU path claims (INTEGRATION.md) is handled somewhere in the flattener
+    assert seen_types >= set(REFERENCE_RECORDS) - {"AABB"}, set(REFERENCE_RECORDS) - seen_types
+    # and the imports name exactly those classes
+    imports = [f for f in walk(forms[0]) if is_list(f, ":import")]
+    imported = {x for f in imports for grp in f[2:] if isinstance(grp, list) for x in grp[2:] if isinstance(x, str)}
+    assert set(REFERENCE_RECORDS) <= imported, set(REFERENCE_RECORDS) - imported
