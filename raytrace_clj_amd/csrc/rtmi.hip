@@ -1230,6 +1230,9 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
                 const int j0 = std::max(0, std::min(G - 1, (int)std::floor((b.lo[2] - 2 * eps - lb.lo[2]) / csz))), j1 = std::max(0, std::min(G - 1, (int)std::floor((b.hi[2] + 2 * eps - lb.lo[2]) / csz)));
                 for (int j = j0; j <= j1; ++j) for (int ii = i0; ii <= i1; ++ii) cell_items[(size_t)j * G + ii].push_back((int)i);
             }
+            size_t claimed = 0;
+            for (const std::vector<int> &ci : cell_items) claimed += ci.size();
+            if (claimed > 4 * layer.size()) cell_items.clear(); // primitives that each span many cells (long sweeps, slabs): the per-cell trees would multiply them -- no grid
             const int depth0 = 6; // stack entries a grid start may already hold: up to grid_kmax cells + the tall tree (+ margin)
             auto subtree = [&](const std::vector<BvhItem> &its) -> int { // child code of a tree over `its`, appended to B.nodes
                 if (its.empty()) return RTMI_BVH_EMPTY;
@@ -1246,15 +1249,15 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
                 }
                 return B.build(b0, b0 + (int)its.size(), depth0);
             };
-            grid_cells.assign((size_t)G * G, RTMI_BVH_EMPTY);
+            if (!cell_items.empty()) grid_cells.assign((size_t)G * G, RTMI_BVH_EMPTY);
             std::vector<BvhItem> tmp;
             for (size_t cidx = 0; cidx < cell_items.size(); ++cidx) {
                 tmp.clear();
                 for (int k : cell_items[cidx]) tmp.push_back(layer[(size_t)k]);
                 grid_cells[cidx] = subtree(tmp);
             }
-            d.grid_tall = subtree(tall);
-            if (B.max_depth >= RTMI_BVH_STACK - 1 || B.nodes.size() / 16 >= (1u << 25)) { // too deep for the stack: no grid (the whole tree above stays valid)
+            if (!cell_items.empty()) d.grid_tall = subtree(tall);
+            if (cell_items.empty() || B.max_depth >= RTMI_BVH_STACK - 1 || B.nodes.size() / 16 >= (1u << 25)) { // too deep for the stack: no grid (the whole tree above stays valid)
                 grid_cells.clear(); d.grid_tall = RTMI_BVH_EMPTY;
             } else {
                 d.grid_n = G;
