@@ -297,6 +297,9 @@ def main():
         def traversal(self):
             return self.pl.slots[0][0].last_traversal_counters()
 
+        def accel_ran(self):
+            return self.pl.slots[0][0].last_accel()
+
         def gather_ms(self):
             return self.tr.last_gather_ms() if multi_proc else None
 
@@ -335,6 +338,9 @@ def main():
             a = [c.last_traversal_counters() for c in self.md.ctxs]
             return sum(x[0] for x in a), sum(x[1] for x in a)
 
+        def accel_ran(self):
+            return self.md.ctxs[0].last_accel()
+
         def gather_ms(self):
             return self.md.last_gather_ms()
 
@@ -357,6 +363,7 @@ def main():
         reduce_ms, reduce_launches = drv.reduce_ms()
         gather_ms = drv.gather_ms() if world > 1 else None
         seg_local, pix_local = drv.counters()
+        accel_ran = drv.accel_ran()  # small mixed-kind scenes answer a request for the tree with the scan (option flat_below)
         segments = seg_local
         if multi_proc:
             coll_dev = "cpu" if rehearsal else "cuda"
@@ -380,7 +387,7 @@ def main():
         launches_per_step = max(1, launches // max(1, steps))
         launch_s = trace_ms / 1e3 / max(1, launches)
         res = {"value": round(samples / (dt / steps) / 1e6, 3), "ms_per_step": round(dt / steps * 1e3, 4), "segments": segments,
-               "segments_per_sample": round(segments / samples, 4),
+               "segments_per_sample": round(segments / samples, 4), "accel_ran": accel_ran,
                "roofline": roofline(cfg_name, accel, args.precision, n_prims, launch_s, launches_per_step, counts, share=1.0 / world)}
         if reduce_launches:  # the one HBM-bound kernel of the path: the in-order per-pixel sample reduction (core.clj:52-53)
             red_s = reduce_ms / 1e3 / reduce_launches
@@ -408,7 +415,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": workload_text(cfg, nx, ny, ns, n_prims, args.accel, world), "nx": nx, "ny": ny, "ns": ns, "spheres": n_prims,
-                       "depth": 50, "accel": args.accel, "frames_in_flight": drv.slots, "segments_per_sample": res["segments_per_sample"],
+                       "depth": 50, "accel": args.accel, "accel_ran": res["accel_ran"], "frames_in_flight": drv.slots, "segments_per_sample": res["segments_per_sample"],
                        "launch_form": "one process per GPU (torch.distributed, RCCL gather)" if multi_proc else
                                       ("one host process, rtmi_render_multi_device (in-library ncclGather)" if in_library else "one GPU")},
             "roofline": res["roofline"],

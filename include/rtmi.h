@@ -98,7 +98,9 @@ int rtmi_shutdown(rtmi_ctx *ctx);
 /* knobs: "accel" (RTMI_ACCEL_*; default RTMI_ACCEL_BVH -- bit-identical to the flat scan), "count_traversal" (0/1: the next
  * renders run the counting instantiation of the BVH kernel, see rtmi_last_traversal_counters), "suspend_lanes" (0..64, default 12: the
  * BVH traversal of a wave stops descending / hands the wave back when fewer lanes than this are still descending / in the tree, and the
- * parked lanes resume in the next trip; 0 = the plain loop; the image does not depend on it), "workspace_bytes" (sample-buffer budget, default 64 GiB, allocated as needed: a frame is rendered in as many sample passes as
+ * parked lanes resume in the next trip; 0 = the plain loop; the image does not depend on it), "flat_below" (default 24: a scene of rectangles /
+ * triangles / instances / media / f4 textures with fewer primitives than this renders through the flat scan even under RTMI_ACCEL_BVH -- same image, a
+ * tree over so few primitives only costs; 0 = never; renders with "count_traversal" always walk the tree), "workspace_bytes" (sample-buffer budget, default 64 GiB, allocated as needed: a frame is rendered in as many sample passes as
  * it takes), "blocks_per_cu" (cap on resident trace workgroups per CU; the launch never exceeds what stays resident),
  * "scan_variant" (flat scan: 0 LDS literal, 1 LDS pipelined, 2 scalar cache, 3 scalar cache + FP32 cull = default),
  * "lds_tile_bytes" (LDS variants), "timing" (0/1 = RTMI_FLAG_TIMING); test hooks: "test_fail_next_render" (the context's next render
@@ -236,6 +238,9 @@ int rtmi_stream_idle(rtmi_ctx *ctx, int32_t *idle);
 /* Sample passes (trace-kernel launches) the context's most recent render took: the per-sample colour buffer is sized by option
  * "workspace_bytes", by the HBM that is free when it has to grow (at most 80 % of it) and, if the allocation still fails, by halving. */
 int rtmi_last_passes(rtmi_ctx *ctx, int32_t *passes);
+/* RTMI_ACCEL_* the context's most recent render actually ran: option "accel" as set, except that a small mixed-kind scene (option
+ * "flat_below") is scanned even when the tree was asked for.  RTMI_E_STATE before the first render. */
+int rtmi_last_accel(rtmi_ctx *ctx, int32_t *accel);
 /* Milliseconds between the end of replica 0's own render and the end of the gather of the last rtmi_render_multi* on
  * replica 0's context (HIP events on its stream): the transfer plus the wait for the slowest replica. */
 int rtmi_last_gather_ms(rtmi_ctx *ctx0, double *ms);

@@ -25,7 +25,7 @@ SYMBOLS = [
     "rtmi_probe_paths", "rtmi_probe_camera", "rtmi_probe_texture", "rtmi_probe_scatter", "rtmi_probe_rng",
     "rtmi_sample_key", "rtmi_probe_arith", "rtmi_probe_math", "rtmi_last_traversal_counters",
     "rtmi_scene_clone", "rtmi_render_multi", "rtmi_render_multi_device", "rtmi_last_gather_ms",
-    "rtmi_last_gather_path", "rtmi_rccl_probe", "rtmi_stream_idle", "rtmi_last_passes",
+    "rtmi_last_gather_path", "rtmi_rccl_probe", "rtmi_stream_idle", "rtmi_last_passes", "rtmi_last_accel",
 ]
 
 F64, F32 = 0, 1
@@ -96,6 +96,7 @@ def lib():
     L.rtmi_rccl_probe.argtypes = [C.c_char_p]
     L.rtmi_stream_idle.argtypes = [vp, C.POINTER(i32)]
     L.rtmi_last_passes.argtypes = [vp, C.POINTER(i32)]
+    L.rtmi_last_accel.argtypes = [vp, C.POINTER(i32)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("rtmi_version",):

@@ -55,6 +55,12 @@ class Context:
         check(_ffi.lib().rtmi_last_trace_ms(self.handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def last_accel(self):
+        """'bvh' or 'flat': what the last render ran (a small mixed-kind scene is scanned even when the tree was asked for: option flat_below)"""
+        v = C.c_int32()
+        check(_ffi.lib().rtmi_last_accel(self.handle, C.byref(v)))
+        return "bvh" if v.value == _ffi.ACCEL_BVH else "flat"
+
     def last_reduce_ms(self):
         """(sum of reduce_kernel ms, launches) of the window the last last_trace_ms() call closed"""
         ms, n = C.c_double(), C.c_int32()

@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# In the tests "accel" means what it says: the library's shortcut for small mixed-kind scenes (option "flat_below": a request for the tree is
+# answered with the flat scan) is switched off, so the tree kernels of those scenes stay under test; the shortcut has its own test.
+os.environ.setdefault("RTMI_FLAT_BELOW", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

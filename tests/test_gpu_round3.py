@@ -446,3 +446,51 @@ def test_media_inside_a_hitlist_match_the_nested_oracle(oracle):
     with pytest.raises(core.RtmiError):
         core.check(r._ffi.lib().rtmi_scene_set_media_mode(ds.handle, 7))
     ds.close(); ctx.close()
+
+
+# ---- small mixed-kind scenes: the scan answers for the tree ----------------------------------------------------------------------------
+def test_small_mixed_scenes_are_scanned_even_when_the_tree_is_asked_for(monkeypatch):
+    """Option "flat_below" (default 24): a Cornell box's 18 primitives render 8 % faster through the flat scan than through a tree, so the
+    library scans them even under accel = BVH -- same image, same counters, and rtmi_last_accel says so.  The tree still runs when its
+    traversal counters are asked for, for larger mixed-kind scenes and for sphere-only scenes of any size."""
+    monkeypatch.delenv("RTMI_FLAT_BELOW", raising=False)  # (conftest switches the shortcut off for every other test)
+    nx, ny, ns = 96, 96, 6
+    cb = fl.flatten(r.scene.make_cornell_box(nx, ny))
+    assert cb.n_prims < 24
+    out = {}
+    for below in (None, 0, 1 << 20):
+        ctx = core.Context(0)
+        ctx.set_option("accel", 1)
+        if below is not None:
+            ctx.set_option("flat_below", below)
+        ds = core.DeviceScene(cb, ctx=ctx)
+        out[below] = ds.render(nx, ny, ns) + (ctx.last_accel(),)
+        if below is None:  # the counting instantiation walks the tree
+            ctx.set_option("count_traversal", 1)
+            cnt = ds.render(nx, ny, ns)
+            assert ctx.last_accel() == "bvh" and ctx.last_traversal_counters()[0] > 0
+            assert np.array_equal(cnt[0], out[None][0])
+        ds.close(); ctx.close()
+    assert out[None][3] == "flat" and out[0][3] == "bvh" and out[1 << 20][3] == "flat"
+    for k in (0, 1 << 20):
+        assert np.array_equal(out[None][0], out[k][0]) and np.array_equal(out[None][1], out[k][1]) and list(out[None][2]) == list(out[k][2])
+    # the flat scan when it was asked for
+    ctx = core.Context(0)
+    ctx.set_option("accel", 0)
+    ds = core.DeviceScene(cb, ctx=ctx)
+    ref = ds.render(nx, ny, ns)
+    assert ctx.last_accel() == "flat" and np.array_equal(ref[0], out[None][0])
+    ds.close(); ctx.close()
+    # not small, or not mixed-kind: the tree
+    for scene in (r.scene.make_final(64, 64), r.scene.make_two_spheres(64, 64), r.scene.make_random_scene(64, 64, 1, False)):
+        ctx = core.Context(0)
+        ds = core.DeviceScene(fl.flatten(scene), ctx=ctx)
+        with pytest.raises(core.RtmiError):
+            ctx.last_accel()  # nothing rendered yet
+        ds.render(64, 64, 2)
+        assert ctx.last_accel() == "bvh"
+        ds.close(); ctx.close()
+    ctx = core.Context(0)
+    with pytest.raises(core.RtmiError):
+        ctx.set_option("flat_below", -1)
+    ctx.close()
