@@ -605,6 +605,7 @@ def test_bench_json_schema():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["value"] > 100
     assert d["config"]["workload"].startswith("C3: 1920x1080x256spp") and d["config"]["spheres"] > 9900 and d["config"]["frames_in_flight"] == 1
+    assert d["config"]["accel"] == "bvh" and d["config"]["accel_ran"] == "bvh"  # what was asked for and what the library ran (small mixed-kind scenes are scanned)
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm", "on_chip_fetch", "launch_ms", "launches_per_step"):
         assert k in rf, k
