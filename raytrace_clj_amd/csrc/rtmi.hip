@@ -166,7 +166,9 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
 template <bool SLICED = false, bool COUNT = false, bool MSEQ = false>
 __device__ inline void intersect_ext(SceneRef, int *, bool, Path<float> &, bool, float, float tmax, float &best_t, int &best_i, bool * = nullptr, int = 0, unsigned * = nullptr) { best_t = tmax; best_i = -1; }
 
-template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICED = false, bool MSEQ = false>
+// NOGRID: the plain (not time-sliced) RENDER kernel -- never launched on a scene with an entry grid, so it carries no code for one (the probe
+// kernels, also not time-sliced, do: they walk a long segment's pieces in a loop of their own)
+template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICED = false, bool MSEQ = false, bool NOGRID = false>
 __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, Path<R> &P,
                                        bool active, R tmin, R tmax, R &best_t, int &best_i, unsigned *cnt = nullptr, bool *mid = nullptr, int min_lanes = 0) {
     if (EXT) { intersect_ext<SLICED, COUNT, MSEQ>(sc, reinterpret_cast<int *>(lds), VARIANT == SCAN_BVH, P, active, tmin, tmax, best_t, best_i, mid, min_lanes, cnt); return; }
@@ -180,7 +182,7 @@ __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per
                 const bool done = scan_bvh<R, COUNT, true>(sc, stack, P, a, tmin, best_t, best_i, [&]() { scan_cull_dispatch(sc, P, a, tmin, best_t, best_i); }, cnt,
                                                            stack + RTMI_BVH_STACK * blockDim.x, *mid, min_lanes);
                 *mid = !done;
-            } else scan_bvh<R, COUNT>(sc, stack, P, a, tmin, best_t, best_i, [&]() { scan_cull_dispatch(sc, P, a, tmin, best_t, best_i); }, cnt);
+            } else scan_bvh<R, COUNT, false, !NOGRID>(sc, stack, P, a, tmin, best_t, best_i, [&]() { scan_cull_dispatch(sc, P, a, tmin, best_t, best_i); }, cnt);
         }
         return;
     }
@@ -366,7 +368,7 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
         // are `mid` segment -- they sit out the shading below and resume where they stopped in the next trip, next to the new
         // segments of the others.  Once the queue is empty nothing is gained by handing back early (suspend_lanes 0).
         R best_t; int best_i;
-        intersect_world<R, MULTI, VARIANT, EXT, COUNT, SLICED, MSEQ>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i, ntrav,
+        intersect_world<R, MULTI, VARIANT, EXT, COUNT, SLICED, MSEQ, !SLICED>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i, ntrav,
                                                                      &mid, exhausted ? 0 : tp.suspend_lanes);
         RTMI_PH(PH_BVH_POST) // intersection: what the phases inside did not book (suspend bookkeeping, call overhead)
         if (!SLICED || __any(alive && !mid)) { // a trip in which no lane finished its segment has nothing to shade
@@ -905,8 +907,9 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             else kern = trace_kernel<double, false, SCAN_SGPR_CULL, true>;
         } else
         switch (variant) {
-        case SCAN_BVH: // suspend_lanes = 0 or a small tree (< 128 inner nodes) selects the instantiation without the time-slicing machinery (the plain while-while loop)
-            if (tp.suspend_lanes > 0 && s->bvh_node_count >= 128) kern = c->count_traversal ? trace_kernel<R, false, SCAN_BVH, false, true> : trace_kernel<R, false, SCAN_BVH>;
+        case SCAN_BVH: // suspend_lanes = 0 or a small tree (< 128 inner nodes) selects the instantiation without the time-slicing machinery (the plain while-while loop);
+                       // a scene with an entry grid always runs the time-sliced one (threshold 0 = never park early): the piecewise walk of long segments lives there
+            if ((tp.suspend_lanes > 0 && s->bvh_node_count >= 128) || s->dev.grid_n > 0) kern = c->count_traversal ? trace_kernel<R, false, SCAN_BVH, false, true> : trace_kernel<R, false, SCAN_BVH>;
             else kern = c->count_traversal ? trace_kernel<R, false, SCAN_BVH, false, true, false> : trace_kernel<R, false, SCAN_BVH, false, false, false>;
             dyn_lds = bvh_lds;
             break;
@@ -1226,7 +1229,10 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
         BvhBox lb = box_empty();
         for (const BvhItem &it : layer) box_grow(lb, it.b);
         const double ex = lb.hi[0] - lb.lo[0], ez = lb.hi[2] - lb.lo[2], ey = lb.hi[1] - lb.lo[1];
-        int G = (int)std::lround(std::sqrt((double)layer.size() / 10.0)); // ~10 primitives per cell (C3: 32 x 32 cells; measured 16 .. 48: 84.1 / 82.3 / 83.3 ms)
+        // ~3.5 primitives per cell (C3: 53 x 53 cells, C2: 12 x 12).  Before long segments were walked in pieces (RTMI_GRID_CHUNK) ~10 per cell was best (C3, 16 .. 48
+        // cells per side: 84.1 / 82.3 / 83.3 ms: a finer grid sent more rays to the root of the whole tree); with the walk 32 / 40 / 48 / 56 / 64 / 72 cells: 77.2 / 76.2 /
+        // 76.4 / 76.1 / 76.7 / 78.5 ms, C2 7 / 10 / 14 / 20 cells: 3.39 / 3.37 / 3.33 / 3.49 ms
+        int G = (int)std::lround(std::sqrt((double)layer.size() / 3.5));
         if (grid_env && std::atoi(grid_env) > 1) G = std::atoi(grid_env);
         G = std::max(2, std::min(G, 96));
         // worth it for a flat, wide layer of many primitives with few tall outliers

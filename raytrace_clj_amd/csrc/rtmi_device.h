@@ -834,6 +834,9 @@ __device__ inline void scan_all_cull(SceneRef sc, const Path<double> &P, double 
 #ifndef RTMI_EXIT_IBALLOT
 #define RTMI_EXIT_IBALLOT 1
 #endif
+#ifndef RTMI_GRID_CHUNK
+#define RTMI_GRID_CHUNK 1 // 1: a segment that crosses more than 2 x 2 grid cells is walked in pieces of at most 2 x 2 cells, nearest piece first (0: it descends from the root of the whole tree)
+#endif
 #define RTMI_BVH_EMPTY ((int)0x80000000) // no child / traversal done; negative like the leaf codes, so "inner node" is one sign test (a leaf code ~(idx | moving << 30) never equals it)
 #ifndef RTMI_BVH_STACK
 #define RTMI_BVH_STACK 32
@@ -1086,13 +1089,22 @@ __device__ inline void bvh_traverse_fmt(SceneRef sc, const BvhRay &r, BvhCursor 
 // their inflated boxes.  A primitive two cells share is tested twice at worst (same t, same index: the any-order rule keeps one).
 // e_rel: rectangle growth relative to |o| + cbound -- RTMI_F32's float sphere test calls a hit up to 3.1e-3 (|o| + cbound) outside the sphere
 // (make_bvh_ray), so its rectangle grows by that much more.
-__device__ inline void bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, float oy, float oz, float dx, float dy, float dz, float best_hi, float e_rel, BvhCursor &cur) {
+// Long segments (RTMI_GRID_CHUNK): a segment whose rectangle is larger is cut at t_split, the parameter up to which it stays within the 2 x 2 cells
+// around its start (1 .. 2 cells of travel along the tighter axis), and only [start, t_split] is entered now -- every primitive it can hit at a
+// t <= t_split overlaps those cells.  The caller traverses them, and if the closest hit so far is not at or before t_split it calls again with
+// t_from = t_split (first = false: the tall primitives' tree, entered with the first piece, is done): an ORDERED walk, nearest piece first, that
+// ends at the first piece holding the hit -- the mean free path of a ray inside the layer is about a cell --, where the descent from the root of
+// the whole tree spends a dozen node visits on locating the ray.  Returns t_split, +inf when this start covers all that remains of the segment.
+__device__ inline float bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, float oy, float oz, float dx, float dy, float dz, float best_hi, float e_rel, BvhCursor &cur,
+                                       float t_from = -__builtin_inff(), bool first = true) {
+    const float kNoSplit = __builtin_inff();
+    float t_split = kNoSplit;
     const int G = sc.grid_n;
     const float bx0 = sc.grid_box[0], by0 = sc.grid_box[1], bz0 = sc.grid_box[2], bx1 = sc.grid_box[3], by1 = sc.grid_box[4], bz1 = sc.grid_box[5];
     // entry plane of an axis = its lo plane for a ray travelling up that axis (shx == 0), else its hi plane; constants as in the node test
-    const float tn = fmaxf(fmaxf(fmaf(r.shx ? bx1 : bx0, r.ixy.x, r.cex), fmaf(r.shy ? by1 : by0, r.ixy.y, r.cey)), fmaxf(fmaf(r.shz ? bz1 : bz0, r.izz.x, r.cez), r.tmin_lo));
+    const float tn = fmaxf(fmaxf(fmaxf(fmaf(r.shx ? bx1 : bx0, r.ixy.x, r.cex), fmaf(r.shy ? by1 : by0, r.ixy.y, r.cey)), fmaxf(fmaf(r.shz ? bz1 : bz0, r.izz.x, r.cez), r.tmin_lo)), t_from);
     const float tf = fminf(fminf(fmaf(r.shx ? bx0 : bx1, r.ixy.x, r.cxx), fmaf(r.shy ? by0 : by1, r.ixy.y, r.cxy)), fminf(fmaf(r.shz ? bz0 : bz1, r.izz.x, r.cxz), best_hi));
-    int tall = sc.grid_tall;
+    int tall = first ? sc.grid_tall : RTMI_BVH_EMPTY;
     if (tall != RTMI_BVH_EMPTY) { // (wave-uniform) the tall primitives' tree: only if the ray meets their box within its range
         const float ux0 = sc.grid_tall_box[0], uy0 = sc.grid_tall_box[1], uz0 = sc.grid_tall_box[2], ux1 = sc.grid_tall_box[3], uy1 = sc.grid_tall_box[4], uz1 = sc.grid_tall_box[5];
         const float un = fmaxf(fmaxf(fmaf(r.shx ? ux1 : ux0, r.ixy.x, r.cex), fmaf(r.shy ? uy1 : uy0, r.ixy.y, r.cey)), fmaxf(fmaf(r.shz ? uz1 : uz0, r.izz.x, r.cez), r.tmin_lo));
@@ -1103,17 +1115,37 @@ __device__ inline void bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, fl
     if (tn <= tf) {
         const float omax = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
         const float e = (omax + sc.bvh_cbound) * e_rel;
-        const float p0x = fmaf(tn, dx, ox), p1x = fmaf(tf, dx, ox), p0z = fmaf(tn, dz, oz), p1z = fmaf(tf, dz, oz);
+        const float p0x = fmaf(tn, dx, ox), p0z = fmaf(tn, dz, oz);
+        float p1x = fmaf(tf, dx, ox), p1z = fmaf(tf, dz, oz);
         const float gmax = (float)(G - 1);
         // cell coordinate = (p - lo) * inv as one fma (p * inv + (-lo * inv)); its rounding (a few 2^-24 of a coordinate <= grid_n) is far below
         // the margin e * inv, which is at least 2^-16 (|o| + cbound) * inv >= 2^-16 of the layer's extent in cells
         const float ax = sc.grid_inv_x, az = sc.grid_inv_z, bx = -sc.grid_lo_x * ax, bz = -sc.grid_lo_z * az, ex = e * ax, ez = e * az;
-        const float fx0 = fmaf(fminf(p0x, p1x), ax, bx) - ex, fx1 = fmaf(fmaxf(p0x, p1x), ax, bx) + ex;
-        const float fz0 = fmaf(fminf(p0z, p1z), az, bz) - ez, fz1 = fmaf(fmaxf(p0z, p1z), az, bz) + ez;
-        const int i0 = (int)fminf(fmaxf(floorf(fx0), 0.0f), gmax), i1 = (int)fminf(fmaxf(floorf(fx1), 0.0f), gmax);
-        const int j0 = (int)fminf(fmaxf(floorf(fz0), 0.0f), gmax), j1 = (int)fminf(fmaxf(floorf(fz1), 0.0f), gmax);
-        const int wi = i1 - i0, wj = j1 - j0;
-        if (!(wi <= 1 && wj <= 1 && (wi + 1) * (wj + 1) <= sc.grid_kmax)) return; // too many cells (or a NaN): the whole tree, from its root
+        const float sx = fmaf(p0x, ax, bx), sz = fmaf(p0z, az, bz); // where the range starts, in cells
+        int i0, i1, j0, j1, wi, wj;
+        auto rect = [&]() { // the cells the rectangle of the range's two end points touches
+            const float qx = fmaf(p1x, ax, bx), qz = fmaf(p1z, az, bz);
+            const float fx0 = fminf(sx, qx) - ex, fx1 = fmaxf(sx, qx) + ex, fz0 = fminf(sz, qz) - ez, fz1 = fmaxf(sz, qz) + ez;
+            i0 = (int)fminf(fmaxf(floorf(fx0), 0.0f), gmax); i1 = (int)fminf(fmaxf(floorf(fx1), 0.0f), gmax);
+            j0 = (int)fminf(fmaxf(floorf(fz0), 0.0f), gmax); j1 = (int)fminf(fmaxf(floorf(fz1), 0.0f), gmax);
+            wi = i1 - i0; wj = j1 - j0;
+            return wi <= 1 && wj <= 1 && (wi + 1) * (wj + 1) <= sc.grid_kmax; // (a NaN: false)
+        };
+        if (!rect()) { // too many cells
+#if RTMI_GRID_CHUNK
+            // the first piece: as far as the range stays inside the two cells per axis that hold its start (and the start's own margin), less 2^-8 of
+            // a cell for the rounding of this very computation -- the rectangle of the piece is then taken from its end points like any other
+            const float gx = dx * ax, gz = dz * az; // cells per unit of t
+            const float lx = gx >= 0.0f ? fminf(fmaxf(floorf(sx - ex), 0.0f), gmax) + (2.0f - 1.0f / 256.0f) - ex : fminf(fmaxf(floorf(sx + ex), 0.0f), gmax) - (1.0f - 1.0f / 256.0f) + ex;
+            const float lz = gz >= 0.0f ? fminf(fmaxf(floorf(sz - ez), 0.0f), gmax) + (2.0f - 1.0f / 256.0f) - ez : fminf(fmaxf(floorf(sz + ez), 0.0f), gmax) - (1.0f - 1.0f / 256.0f) + ez;
+            const float ts = tn + fminf((lx - sx) * __builtin_amdgcn_rcpf(gx), (lz - sz) * __builtin_amdgcn_rcpf(gz));
+            p1x = fmaf(ts, dx, ox); p1z = fmaf(ts, dz, oz);
+            if (!(ts > tn && ts < tf && sc.grid_kmax >= 4 && rect())) return kNoSplit; // (cannot happen for margins far below a cell; if it does: the whole tree, from its root)
+            t_split = ts;
+#else
+            return kNoSplit; // the whole tree, from its root
+#endif
+        }
         const int *cells = sc.grid_cells;
         const int a00 = cells[j0 * G + i0], a10 = cells[j0 * G + i1], a01 = cells[j1 * G + i0], a11 = cells[j1 * G + i1]; // four loads in flight (duplicates when the rectangle is narrower)
         // the cell the segment starts in goes first (its hits prune the others)
@@ -1129,7 +1161,7 @@ __device__ inline void bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, fl
         c1 = (wi == 0 || k == 1) ? RTMI_BVH_EMPTY : a10;
         c2 = (wj == 0 || k == 2) ? RTMI_BVH_EMPTY : a01;
         c3 = (wi == 0 || wj == 0 || k == 3) ? RTMI_BVH_EMPTY : a11;
-    } else if (!(tn > tf)) return; // (a NaN cannot arise for a ray make_bvh_ray accepted; if it did: the whole tree)
+    } else if (!(tn > tf)) return kNoSplit; // (a NaN cannot arise for a ray make_bvh_ray accepted; if it did: the whole tree)
     // else: the ray does not meet the layer's box within its range -- only the tall primitives remain
     const int stride = blockDim.x;
     int node = RTMI_BVH_EMPTY, tos = cur.tos, *top = cur.top;
@@ -1141,6 +1173,7 @@ __device__ inline void bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, fl
     };
     add(tall); add(c3); add(c2); add(c1); add(c0); add(near);
     cur.node = node; cur.tos = tos; cur.top = top;
+    return t_split;
 }
 
 // one loop per record format (a format test inside the loop costs 5 %)
@@ -1164,20 +1197,33 @@ template <> __device__ inline float best_from_words<float>(int w0, int) { return
 // Time-sliced use (susp != nullptr; min_lanes as in bvh_traverse_fmt): returns false when the lane's traversal was suspended -- its
 // cursor and closest hit so far are then in susp (RTMI_BVH_SUSPEND_WORDS columns of blockDim.x words) -- and the caller passes
 // resume = true on the next call with the SAME ray; best_t / best_i are only final when the function returns true.
-template <typename R, bool COUNT = false, bool SLICE = false, typename Flat>
+// CHUNK = false: the instantiation for scenes WITHOUT an entry grid (the plain render kernel: it is never launched on a scene that has one)
+template <typename R, bool COUNT = false, bool SLICE = false, bool CHUNK = true, typename Flat>
 __device__ inline bool scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, R tmin, R &best_t, int &best_i, Flat flat, unsigned *cnt = nullptr,
                                 int *susp = nullptr, bool resume = false, int min_lanes = 0) {
+    constexpr bool WALK = CHUNK && RTMI_GRID_CHUNK;
     const bool behind_ok = tmin >= R(0);
     const double *exact12 = sc.exact12;
     const BvhRay r = make_bvh_ray<R>(sc, P, a, tmin); // a function of the ray: a resumed lane gets the values it had
     const int stride = blockDim.x;
     int *sw = susp + threadIdx.x;
     BvhCursor cur;
+    // RTMI_GRID_CHUNK: a long segment is walked piece by piece (bvh_grid_entry).  t_split = where the piece being traversed ends (+inf: it is the
+    // last one); it rides in a register while the lane is in the tree and in level 0 of the lane's stack column (a slot the traversal only ever
+    // reads, for the pop of the sentinel) while the lane is parked.  A lane whose piece is finished without the hit being settled parks with
+    // `top` = -1 and resumes with the next piece: the grid entry then runs at full width next to the new segments of the other lanes.
+    float t_split = __builtin_inff(), t_from = -__builtin_inff();
+    bool reenter = false;
     if (SLICE && resume) {
         cur.node = sw[0]; cur.tos = sw[stride];
-        cur.top = reinterpret_cast<int *>(reinterpret_cast<char *>(stack) + sw[2 * stride]);
+        const int top_off = sw[2 * stride];
+        cur.top = reinterpret_cast<int *>(reinterpret_cast<char *>(stack) + top_off);
         best_t = best_from_words<R>(sw[3 * stride], sw[4 * stride]);
         best_i = sw[5 * stride];
+        if (WALK) {
+            t_split = __int_as_float(stack[threadIdx.x]);
+            if (top_off < 0) { reenter = true; t_from = t_split; t_split = __builtin_inff(); cur = bvh_cursor_at_root(sc, stack); }
+        }
     } else {
         if (!r.ok) { // rays the float traversal cannot bound take the exact flat scan (all primitives, original order) instead
             if (COUNT) cnt[1] += (unsigned)sc.n_all;
@@ -1196,17 +1242,33 @@ __device__ inline bool scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, 
     // 2. the tree
     auto leaf = [&](int code) { exact_prim_test_lane<R>(exact12, code, P, qa, tmin, behind_ok, best_t, best_i); };
     auto best = [&]() { return (best_t < R(3.0e38) ? float_up((double)best_t) : 3.4028235e38f) + 0.0f; };
-    if (sc.grid_n && !(SLICE && resume)) // where the traversal starts: the roots of the grid cells the ray's segment crosses, or the root of the whole tree
-        bvh_grid_entry(sc, r, (float)P.ox, (float)P.oy, (float)P.oz, (float)P.dx, (float)P.dy, (float)P.dz, best(),
-                       sizeof(R) == sizeof(float) ? 4.0e-3f + 1.0f / 65536.0f : 1.0f / 65536.0f, cur);
-    bvh_traverse<COUNT, SLICE>(sc, r, cur, min_lanes, leaf, best, cnt);
-    if (SLICE && cur.node != RTMI_BVH_EMPTY) { // suspended
-        int w0, w1;
-        best_to_words<R>(best_t, w0, w1);
-        sw[0] = cur.node; sw[stride] = cur.tos;
-        sw[2 * stride] = (int)(reinterpret_cast<char *>(cur.top) - reinterpret_cast<char *>(stack));
-        sw[3 * stride] = w0; sw[4 * stride] = w1; sw[5 * stride] = best_i;
-        return false;
+    const float e_rel = sizeof(R) == sizeof(float) ? 4.0e-3f + 1.0f / 65536.0f : 1.0f / 65536.0f;
+    bool enter = CHUNK && sc.grid_n && (!(SLICE && resume) || reenter), first = !reenter;
+    for (;;) {
+        if (enter) // where the traversal starts: the roots of the grid cells the ray's segment (or its next piece) crosses, or the root of the whole tree
+            t_split = bvh_grid_entry(sc, r, (float)P.ox, (float)P.oy, (float)P.oz, (float)P.dx, (float)P.dy, (float)P.dz, best(), e_rel, cur, t_from, first);
+        bvh_traverse<COUNT, SLICE>(sc, r, cur, min_lanes, leaf, best, cnt);
+        if (SLICE && cur.node != RTMI_BVH_EMPTY) { // suspended
+            int w0, w1;
+            best_to_words<R>(best_t, w0, w1);
+            sw[0] = cur.node; sw[stride] = cur.tos;
+            sw[2 * stride] = (int)(reinterpret_cast<char *>(cur.top) - reinterpret_cast<char *>(stack));
+            sw[3 * stride] = w0; sw[4 * stride] = w1; sw[5 * stride] = best_i;
+            if (WALK) stack[threadIdx.x] = __float_as_int(t_split);
+            return false;
+        }
+        if (!WALK) break;
+        if (!(best_t > (R)t_split)) break; // the hit is settled: whatever the later pieces hold lies beyond t_split (always, when there is no later piece: +inf)
+        if (SLICE) { // the next piece is entered next trip, at full width
+            int w0, w1;
+            best_to_words<R>(best_t, w0, w1);
+            sw[0] = RTMI_BVH_EMPTY; sw[stride] = RTMI_BVH_EMPTY; sw[2 * stride] = -1;
+            sw[3 * stride] = w0; sw[4 * stride] = w1; sw[5 * stride] = best_i;
+            stack[threadIdx.x] = __float_as_int(t_split);
+            return false;
+        }
+        cur = bvh_cursor_at_root(sc, stack);
+        t_from = t_split; first = false; enter = true; // (probes: the next piece right away)
     }
     // 3. a ray outside the shutter interval: the MovingSphere boxes were built for [t_lo, t_hi], so test every moving sphere exactly
     if (!r.time_ok)
