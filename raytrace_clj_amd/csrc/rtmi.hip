@@ -1273,6 +1273,21 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
                 grid_cells[cidx] = subtree(tmp);
             }
             if (!cell_items.empty()) d.grid_tall = subtree(tall);
+            { // a cell without primitives points at ONE shared node whose two boxes are empty (a visit that hits nothing and pops): the device pushes a
+              // segment's cell roots without testing them for "no tree" (bvh_grid_entry), and an RTMI_BVH_EMPTY on the stack would end the traversal
+                int null_node = -1;
+                for (int &c : grid_cells) if (c == RTMI_BVH_EMPTY) {
+                    if (null_node < 0) {
+                        const int node = (int)(B.nodes.size() / 16);
+                        B.nodes.resize(B.nodes.size() + 16, 0.0f);
+                        B.put_empty_box(node, 0); B.put_empty_box(node, 1);
+                        const int e = RTMI_BVH_EMPTY;
+                        std::memcpy(&B.nodes[(size_t)node * 16 + 12], &e, 4); std::memcpy(&B.nodes[(size_t)node * 16 + 13], &e, 4);
+                        null_node = node * 64;
+                    }
+                    c = null_node;
+                }
+            }
             if (cell_items.empty() || B.max_depth >= RTMI_BVH_STACK - 1 || B.nodes.size() / 16 >= (1u << 25)) { // too deep for the stack: no grid (the whole tree above stays valid)
                 grid_cells.clear(); d.grid_tall = RTMI_BVH_EMPTY;
             } else {

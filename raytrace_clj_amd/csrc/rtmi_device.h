@@ -828,9 +828,6 @@ __device__ inline void scan_all_cull(SceneRef sc, const Path<double> &P, double 
 // ---- RTMI_ACCEL_BVH: per-lane BVH traversal with conservative float boxes, exact FP64 leaves -------------------------
 // Closest hit is order independent: candidate(prim) = first root if > t-min else second root (hitable.clj:192-207 with the
 // running t-max of hitable.clj:20 only ever rejecting non-minimal candidates); ties -> lowest Hitlist index (first wins).
-#ifndef RTMI_GRID_NEAR
-#define RTMI_GRID_NEAR 0 // 1: the cell a segment starts in is visited first (its hits would prune the others) -- measured: the ordering's own instructions cost more than the pruning saves (C3 77.9 vs 77.6 ms without)
-#endif
 #ifndef RTMI_EXIT_IBALLOT
 #define RTMI_EXIT_IBALLOT 1
 #endif
@@ -1111,7 +1108,8 @@ __device__ inline float bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, f
         const float uf = fminf(fminf(fmaf(r.shx ? ux0 : ux1, r.ixy.x, r.cxx), fmaf(r.shy ? uy0 : uy1, r.ixy.y, r.cxy)), fminf(fmaf(r.shz ? uz0 : uz1, r.izz.x, r.cxz), best_hi));
         tall = un > uf ? RTMI_BVH_EMPTY : tall; // (a NaN keeps the tree)
     }
-    int c0 = RTMI_BVH_EMPTY, c1 = RTMI_BVH_EMPTY, c2 = RTMI_BVH_EMPTY, c3 = RTMI_BVH_EMPTY, near = RTMI_BVH_EMPTY;
+    const int stride = blockDim.x;
+    int node = RTMI_BVH_EMPTY, tos = cur.tos, *top = cur.top;
     if (tn <= tf) {
         const float omax = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
         const float e = (omax + sc.bvh_cbound) * e_rel;
@@ -1148,30 +1146,19 @@ __device__ inline float bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, f
         }
         const int *cells = sc.grid_cells;
         const int a00 = cells[j0 * G + i0], a10 = cells[j0 * G + i1], a01 = cells[j1 * G + i0], a11 = cells[j1 * G + i1]; // four loads in flight (duplicates when the rectangle is narrower)
-        // the cell the segment starts in goes first (its hits prune the others)
-#if RTMI_GRID_NEAR
-        const int ni = ((int)fminf(fmaxf(floorf(fmaf(p0x, ax, bx)), (float)i0), (float)i1)) - i0;
-        const int nj = ((int)fminf(fmaxf(floorf(fmaf(p0z, az, bz)), (float)j0), (float)j1)) - j0;
-        const int k = ni + 2 * nj;
-#else
-        const int k = 0;
-#endif
-        near = k == 0 ? a00 : (k == 1 ? a10 : (k == 2 ? a01 : a11));
-        c0 = k == 0 ? RTMI_BVH_EMPTY : a00;
-        c1 = (wi == 0 || k == 1) ? RTMI_BVH_EMPTY : a10;
-        c2 = (wj == 0 || k == 2) ? RTMI_BVH_EMPTY : a01;
-        c3 = (wi == 0 || wj == 0 || k == 3) ? RTMI_BVH_EMPTY : a11;
+        // The roots go onto the stack without a branch: every cell has a tree (the host gives the empty ones a shared node that hits nothing), so which
+        // codes are pushed is a function of the rectangle's shape alone -- 1 x 1: a00;  2 x 1: a10, a00;  1 x 2: a01, a00;  2 x 2: a11, a01, a10, a00 (bottom
+        // to top; a00 is visited first).  The three stores are unconditional: what they leave above the new top is never read.
+        top[0] = tos; top[stride] = a11; top[2 * stride] = a01;
+        tos = wi ? a10 : (wj ? a01 : tos);
+        top += (wi + wj + wi * wj) * stride;
+        node = a00;
     } else if (!(tn > tf)) return kNoSplit; // (a NaN cannot arise for a ray make_bvh_ray accepted; if it did: the whole tree)
     // else: the ray does not meet the layer's box within its range -- only the tall primitives remain
-    const int stride = blockDim.x;
-    int node = RTMI_BVH_EMPTY, tos = cur.tos, *top = cur.top;
-    auto add = [&](int code) { // the code added last is visited first
-        if (code != RTMI_BVH_EMPTY) {
-            if (node != RTMI_BVH_EMPTY) { *top = tos; top += stride; tos = node; }
-            node = code;
-        }
-    };
-    add(tall); add(c3); add(c2); add(c1); add(c0); add(near);
+    if (tall != RTMI_BVH_EMPTY) { // (few lanes: the tall primitives' box is small) visited first
+        if (node != RTMI_BVH_EMPTY) { *top = tos; top += stride; tos = node; }
+        node = tall;
+    }
     cur.node = node; cur.tos = tos; cur.top = top;
     return t_split;
 }
