@@ -38,10 +38,7 @@ using namespace rtmi;
 // =====================================================================================================
 namespace {
 
-constexpr int kBlock = 256;
-#ifndef RTMI_TRACE_BLOCK
-#define RTMI_TRACE_BLOCK 256
-#endif
+constexpr int kBlock = RTMI_TRACE_BLOCK;      // (the probe kernels traverse the tree too: same workgroup size as the trace kernel, see RTMI_BVH_STRIDE)
 constexpr int kTraceBlock = RTMI_TRACE_BLOCK; // threads per workgroup of the trace kernel
 // Diagnostic build only (make stamps -> librtmi_stamps.so): per-phase wave ticks and lane-ticks (ph_stamp, rtmi_device.h), summed over the
 // launch's waves into g_phase and printed to stderr after every render, with the workgroups' start / end times.  Never defined in the
@@ -153,7 +150,7 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
     }
     if (bvh) {
         if (SLICED) { // time-sliced: a suspended lane's media are evaluated (and draw) when its traversal completes, as in the plain loop
-            const bool done = scan_bvh_ext<true, COUNT>(sc, stack, P, a, tmin, H, stack + RTMI_BVH_STACK * blockDim.x, *mid, min_lanes, cnt);
+            const bool done = scan_bvh_ext<true, COUNT>(sc, stack, P, a, tmin, H, stack + RTMI_BVH_STACK * RTMI_BVH_STRIDE, *mid, min_lanes, cnt);
             *mid = !done;
             if (!done) return;
         } else scan_bvh_ext<false, COUNT>(sc, stack, P, a, tmin, H, nullptr, false, 0, cnt);
@@ -180,7 +177,7 @@ __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per
         if (active) {
             if (SLICED) {
                 const bool done = scan_bvh<R, COUNT, true>(sc, stack, P, a, tmin, best_t, best_i, [&]() { scan_cull_dispatch(sc, P, a, tmin, best_t, best_i); }, cnt,
-                                                           stack + RTMI_BVH_STACK * blockDim.x, *mid, min_lanes);
+                                                           stack + RTMI_BVH_STACK * RTMI_BVH_STRIDE, *mid, min_lanes);
                 *mid = !done;
             } else scan_bvh<R, COUNT, false, !NOGRID>(sc, stack, P, a, tmin, best_t, best_i, [&]() { scan_cull_dispatch(sc, P, a, tmin, best_t, best_i); }, cnt);
         }

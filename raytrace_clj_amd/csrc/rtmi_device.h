@@ -838,6 +838,12 @@ __device__ inline void scan_all_cull(SceneRef sc, const Path<double> &P, double 
 #ifndef RTMI_BVH_STACK
 #define RTMI_BVH_STACK 32
 #endif
+// threads per workgroup of EVERY kernel that traverses the tree (trace and probe kernels are launched with exactly this many): the stride of the
+// stack / parked-cursor columns in LDS is then a constant, i.e. an immediate offset of the ds_ instructions instead of address arithmetic
+#ifndef RTMI_TRACE_BLOCK
+#define RTMI_TRACE_BLOCK 256
+#endif
+#define RTMI_BVH_STRIDE RTMI_TRACE_BLOCK
 
 template <typename R, typename A>
 __device__ inline void sphere_roots_any_order(R bq, R cq, R disc, const A &a, R tmin, bool behind_ok, R &best_t, int &best_i, int idx) {
@@ -966,7 +972,7 @@ __device__ unsigned long long g_phase[48]; // [0..15] wave ticks per phase, [16.
 // emptiness test and the LDS read of a pop is only needed by the NEXT pop or push: its latency is off the critical path.  (The
 // tree's depth is < RTMI_BVH_STACK - 1 by construction; level 0 is only ever READ, by the pop of the sentinel.)
 struct BvhCursor { int node, tos; int *top; };
-__device__ inline BvhCursor bvh_cursor_at_root(SceneRef sc, int *stack) { return BvhCursor{sc.bvh_root, RTMI_BVH_EMPTY, stack + blockDim.x + threadIdx.x}; }
+__device__ inline BvhCursor bvh_cursor_at_root(SceneRef sc, int *stack) { return BvhCursor{sc.bvh_root, RTMI_BVH_EMPTY, stack + RTMI_BVH_STRIDE + threadIdx.x}; }
 
 // SLICE: TIME-SLICED traversal.  A few rays of a wave visit ten times the nodes the others do (C2: 42 % of the descent trips and 40 % of
 // the exact-test phases served fewer than 8 lanes, 20 % a single lane).  Two rules, one threshold: (1) the descent loop stops as soon
@@ -979,7 +985,7 @@ template <bool NODE16, bool COUNT, bool SLICE, typename Leaf, typename BestHi>
 __device__ inline void bvh_traverse_fmt(SceneRef sc, const BvhRay &r, BvhCursor &cur, int min_lanes, Leaf leaf, BestHi best, unsigned *cnt) {
     int node = cur.node;
     if (node == RTMI_BVH_EMPTY) return;
-    const int stride = blockDim.x;
+    constexpr int stride = RTMI_BVH_STRIDE;
     int *top = cur.top;
     int tos = cur.tos;
     const char *nodes = reinterpret_cast<const char *>(sc.bvh_nodes);
@@ -1108,7 +1114,7 @@ __device__ inline float bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, f
         const float uf = fminf(fminf(fmaf(r.shx ? ux0 : ux1, r.ixy.x, r.cxx), fmaf(r.shy ? uy0 : uy1, r.ixy.y, r.cxy)), fminf(fmaf(r.shz ? uz0 : uz1, r.izz.x, r.cxz), best_hi));
         tall = un > uf ? RTMI_BVH_EMPTY : tall; // (a NaN keeps the tree)
     }
-    const int stride = blockDim.x;
+    constexpr int stride = RTMI_BVH_STRIDE;
     int node = RTMI_BVH_EMPTY, tos = cur.tos, *top = cur.top;
     if (tn <= tf) {
         const float omax = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
@@ -1192,7 +1198,7 @@ __device__ inline bool scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, 
     const bool behind_ok = tmin >= R(0);
     const double *exact12 = sc.exact12;
     const BvhRay r = make_bvh_ray<R>(sc, P, a, tmin); // a function of the ray: a resumed lane gets the values it had
-    const int stride = blockDim.x;
+    constexpr int stride = RTMI_BVH_STRIDE;
     int *sw = susp + threadIdx.x;
     BvhCursor cur;
     // RTMI_GRID_CHUNK: a long segment is walked piece by piece (bvh_grid_entry).  t_split = where the piece being traversed ends (+inf: it is the
@@ -1456,7 +1462,7 @@ template <bool SLICE = false, bool COUNT = false>
 __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, ExtHit &H, int *susp = nullptr, bool resume = false,
                                     int min_lanes = 0, unsigned *cnt = nullptr, int lo = 0, int hi = 0x7fffffff) {
     const BvhRay r = make_bvh_ray(sc, P, a, tmin);
-    const int stride = blockDim.x;
+    constexpr int stride = RTMI_BVH_STRIDE;
     int *sw = susp + threadIdx.x;
     BvhCursor cur;
     if (SLICE && resume) {
