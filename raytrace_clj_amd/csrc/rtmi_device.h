@@ -916,6 +916,10 @@ __device__ inline bool slab_hit(const v2f a, const v2f b, const v2f z, const flo
 }
 
 __device__ inline float min_raw(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// a float >= x within two ulps (any finite x; values beyond FLT_MAX give FLT_MAX, as the closest hit so far never exceeds the caller's t-max = Float/MAX_VALUE):
+// RN(x) is within 2^-24 |x| (2^-150 in the denormal range) of x, so RN(x) (1 + 2^-23) + 2^-120 is above it.  Used for the traversal's bound of the closest
+// hit so far, refreshed after every exact-test phase: a bound needs no exactness, and the exact form (float_up) is a dozen instructions and a branch.
+__device__ inline float float_above(double x) { const float f = (float)x; return fminf(fmaf(fabsf(f), 0x1p-23f, f) + 0x1p-120f, 3.4028235e38f); }
 __device__ inline float float_up(double x) { // smallest float >= x (x finite, |x| < FLT_MAX)
     float f = (float)x;
     if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + (f >= 0.0f ? 1u : (unsigned)-1));
@@ -1234,7 +1238,7 @@ __device__ inline bool scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, 
     }
     // 2. the tree
     auto leaf = [&](int code) { exact_prim_test_lane<R>(exact12, code, P, qa, tmin, behind_ok, best_t, best_i); };
-    auto best = [&]() { return (best_t < R(3.0e38) ? float_up((double)best_t) : 3.4028235e38f) + 0.0f; };
+    auto best = [&]() { return float_above((double)best_t); };
     const float e_rel = sizeof(R) == sizeof(float) ? 4.0e-3f + 1.0f / 65536.0f : 1.0f / 65536.0f;
     bool enter = CHUNK && sc.grid_n && (!(SLICE && resume) || reenter), first = !reenter;
     for (;;) {
@@ -1453,7 +1457,7 @@ __device__ inline void scan_all_cull_ext(SceneRef sc, const Path<double> &P, dou
     }
 }
 
-__device__ inline float ext_best_hi(const ExtHit &H) { return (H.t < 3.0e38 ? float_up(H.t) : 3.4028235e38f) + 0.0f; }
+__device__ inline float ext_best_hi(const ExtHit &H) { return float_above(H.t); }
 
 // Time-sliced like scan_bvh (susp: RTMI_BVH_SUSPEND_WORDS_EXT columns behind the stack; returns false when the lane's traversal was
 // suspended): the mixed-kind scenes need it most -- make-final's descent trips ran at 12.7 of 64 lanes, 66 % of them below 8.
