@@ -1246,7 +1246,7 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
             size_t claimed = 0;
             for (const std::vector<int> &ci : cell_items) claimed += ci.size();
             if (claimed > 4 * layer.size()) cell_items.clear(); // primitives that each span many cells (long sweeps, slabs): the per-cell trees would multiply them -- no grid
-            const int depth0 = 6; // stack entries a grid start may already hold: up to grid_kmax cells + the tall tree (+ margin)
+            const int depth0 = 3; // stack entries a grid start may already hold: the rectangle's tree under the tall tree (+ margin)
             auto subtree = [&](const std::vector<BvhItem> &its) -> int { // child code of a tree over `its`, appended to B.nodes
                 if (its.empty()) return RTMI_BVH_EMPTY;
                 const int b0 = (int)B.items.size();
@@ -1262,29 +1262,25 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
                 }
                 return B.build(b0, b0 + (int)its.size(), depth0);
             };
-            if (!cell_items.empty()) grid_cells.assign((size_t)G * G, RTMI_BVH_EMPTY);
+            // One tree per RECTANGLE of cells a segment can touch -- 1 x 1, 2 x 1, 1 x 2, 2 x 2 (four families, each indexed by the rectangle's low corner:
+            // grid_cells[(wi + 2 wj) G G + j0 G + i0]) -- over the union of the cells' primitives: a segment starts at ONE root (no root per cell to push and
+            // to visit), and a primitive two cells of the rectangle share is in the tree once (it used to be tested exactly once per cell).
+            if (!cell_items.empty()) grid_cells.assign((size_t)4 * G * G, RTMI_BVH_EMPTY);
             std::vector<BvhItem> tmp;
-            for (size_t cidx = 0; cidx < cell_items.size(); ++cidx) {
-                tmp.clear();
-                for (int k : cell_items[cidx]) tmp.push_back(layer[(size_t)k]);
-                grid_cells[cidx] = subtree(tmp);
-            }
-            if (!cell_items.empty()) d.grid_tall = subtree(tall);
-            { // a cell without primitives points at ONE shared node whose two boxes are empty (a visit that hits nothing and pops): the device pushes a
-              // segment's cell roots without testing them for "no tree" (bvh_grid_entry), and an RTMI_BVH_EMPTY on the stack would end the traversal
-                int null_node = -1;
-                for (int &c : grid_cells) if (c == RTMI_BVH_EMPTY) {
-                    if (null_node < 0) {
-                        const int node = (int)(B.nodes.size() / 16);
-                        B.nodes.resize(B.nodes.size() + 16, 0.0f);
-                        B.put_empty_box(node, 0); B.put_empty_box(node, 1);
-                        const int e = RTMI_BVH_EMPTY;
-                        std::memcpy(&B.nodes[(size_t)node * 16 + 12], &e, 4); std::memcpy(&B.nodes[(size_t)node * 16 + 13], &e, 4);
-                        null_node = node * 64;
-                    }
-                    c = null_node;
+            std::vector<int> uni;
+            for (int fam = 0; fam < 4 && !cell_items.empty(); ++fam) {
+                const int wi = fam & 1, wj = fam >> 1;
+                for (int j = 0; j + wj < G; ++j) for (int i = 0; i + wi < G; ++i) {
+                    uni.clear();
+                    for (int dj = 0; dj <= wj; ++dj) for (int di = 0; di <= wi; ++di) { const std::vector<int> &ci = cell_items[(size_t)(j + dj) * G + i + di]; uni.insert(uni.end(), ci.begin(), ci.end()); }
+                    std::sort(uni.begin(), uni.end());
+                    uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+                    tmp.clear();
+                    for (int k : uni) tmp.push_back(layer[(size_t)k]);
+                    grid_cells[(size_t)fam * G * G + (size_t)j * G + i] = subtree(tmp);
                 }
             }
+            if (!cell_items.empty()) d.grid_tall = subtree(tall);
             if (cell_items.empty() || B.max_depth >= RTMI_BVH_STACK - 1 || B.nodes.size() / 16 >= (1u << 25)) { // too deep for the stack: no grid (the whole tree above stays valid)
                 grid_cells.clear(); d.grid_tall = RTMI_BVH_EMPTY;
             } else {

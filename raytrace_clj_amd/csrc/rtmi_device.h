@@ -50,7 +50,7 @@ struct DevScene {
     float grid_box[6];       // lo.xyz hi.xyz of the layer primitives' boxes (rounded outward like every node box): a ray's t range inside it
     float grid_tall_box[6];  // the same for the tall primitives: their tree is entered only by rays that meet this box
     float grid_eps;          // the cell rectangle of a segment is grown by this much (float position error, far below a cell)
-    const int *grid_cells;   // [grid_n * grid_n] root codes (row = z cell, column = x cell)
+    const int *grid_cells;   // [4][grid_n][grid_n] root codes: family wi + 2 wj = the tree over the (1 + wi) x (1 + wj) cells whose low corner is (row = z cell, column = x cell)
     // section 8(f3): rectangles / triangles and FlipNormals / Translate / RotateY instances (hitable.clj:269-511, 548-581)
     int has_ext;             // any primitive kind > 2, any instance wrapper, any flip
     const int *ext_info;     // [n_all][4]: kind, FlipNormals parity, first xform, xform count (outermost first)
@@ -1154,15 +1154,9 @@ __device__ inline float bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, f
             return kNoSplit; // the whole tree, from its root
 #endif
         }
-        const int *cells = sc.grid_cells;
-        const int a00 = cells[j0 * G + i0], a10 = cells[j0 * G + i1], a01 = cells[j1 * G + i0], a11 = cells[j1 * G + i1]; // four loads in flight (duplicates when the rectangle is narrower)
-        // The roots go onto the stack without a branch: every cell has a tree (the host gives the empty ones a shared node that hits nothing), so which
-        // codes are pushed is a function of the rectangle's shape alone -- 1 x 1: a00;  2 x 1: a10, a00;  1 x 2: a01, a00;  2 x 2: a11, a01, a10, a00 (bottom
-        // to top; a00 is visited first).  The three stores are unconditional: what they leave above the new top is never read.
-        top[0] = tos; top[stride] = a11; top[2 * stride] = a01;
-        tos = wi ? a10 : (wj ? a01 : tos);
-        top += (wi + wj + wi * wj) * stride;
-        node = a00;
+        // ONE root: the host built a tree for every rectangle of cells (1 x 1, 2 x 1, 1 x 2, 2 x 2: family wi + 2 wj, indexed by the low corner) over the union
+        // of the cells' primitives -- nothing to push, no root per cell to visit, and a primitive two of the cells share is tested once
+        node = sc.grid_cells[((wi + 2 * wj) * G + j0) * G + i0];
     } else if (!(tn > tf)) return kNoSplit; // (a NaN cannot arise for a ray make_bvh_ray accepted; if it did: the whole tree)
     // else: the ray does not meet the layer's box within its range -- only the tall primitives remain
     if (tall != RTMI_BVH_EMPTY) { // (few lanes: the tall primitives' box is small) visited first
