@@ -1155,6 +1155,18 @@ bool prim_world_box(int kind, const double *g, const int32_t *xf_kind, const dou
     return true;
 }
 
+// the IEEE half at or beyond x in the given direction (up: >= x, else <= x); beyond the half range: +-inf
+static uint16_t half_outward(float x, bool up) {
+    _Float16 h = (_Float16)x;
+    uint16_t b; std::memcpy(&b, &h, 2);
+    const float back = (float)h;
+    if (up ? (back < x) : (back > x)) { // step to the next half outward
+        if (b == 0x0000 || b == 0x8000) b = up ? 0x0001 : 0x8001;
+        else if ((b & 0x8000) ? !up : up) b += 1; // away from zero
+        else b -= 1;                               // towards zero
+    }
+    return b;
+}
 // fills d.bvh_* ; returns the node array to upload.  wbox[i] / bounded[i]: prim_world_box of every primitive.
 std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, const std::vector<BvhBox> &wbox, const std::vector<char> &bounded, const double *cam,
                              bool want_grid, std::vector<int> &grid_cells) {
@@ -1293,22 +1305,16 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
                 BvhBox tb = box_empty();
                 for (const BvhItem &it : tall) box_grow(tb, it.b);
                 for (int k = 0; k < 3; ++k) { d.grid_tall_box[k] = tall.empty() ? 0.0f : f_down(tb.lo[k] - B.delta - eps); d.grid_tall_box[3 + k] = tall.empty() ? 0.0f : f_up(tb.hi[k] + B.delta + eps); }
+                for (int k = 0; k < 3; ++k) { // what the device tests: {lo, hi} half pairs, rounded outward once more
+                    d.grid_box_h[k] = (unsigned)half_outward(d.grid_box[k], false) | ((unsigned)half_outward(d.grid_box[3 + k], true) << 16);
+                    d.grid_tall_box_h[k] = (unsigned)half_outward(d.grid_tall_box[k], false) | ((unsigned)half_outward(d.grid_tall_box[3 + k], true) << 16);
+                }
             }
         }
     }
     d.bvh_node16 = 0;
     if (d.bvh_root != RTMI_BVH_EMPTY) { // 32-byte records (Node16) when rounding the planes to half costs little: 12 halves + 2 child codes
-        auto half_bits = [](float x, bool up) {
-            _Float16 h = (_Float16)x;
-            uint16_t b; std::memcpy(&b, &h, 2);
-            const float back = (float)h;
-            if (up ? (back < x) : (back > x)) { // step to the next half outward
-                if (b == 0x0000 || b == 0x8000) b = up ? 0x0001 : 0x8001;
-                else if ((b & 0x8000) ? !up : up) b += 1; // away from zero
-                else b -= 1;                               // towards zero
-            }
-            return b;
-        };
+        auto half_bits = [](float x, bool up) { return half_outward(x, up); };
         auto half_val = [](uint16_t b) { _Float16 h; std::memcpy(&h, &b, 2); return (double)(float)h; };
         std::vector<float> out(B.nodes.size() / 2, 0.0f);
         double area32 = 0.0, area16 = 0.0;

@@ -50,6 +50,7 @@ struct DevScene {
     float grid_box[6];       // lo.xyz hi.xyz of the layer primitives' boxes (rounded outward like every node box): a ray's t range inside it
     float grid_tall_box[6];  // the same for the tall primitives: their tree is entered only by rays that meet this box
     float grid_eps;          // the cell rectangle of a segment is grown by this much (float position error, far below a cell)
+    unsigned grid_box_h[3], grid_tall_box_h[3]; // the two boxes again, per axis a {lo, hi} pair of IEEE halves rounded outward (like a Node16's planes): what the device tests
     const int *grid_cells;   // [4][grid_n][grid_n] root codes: family wi + 2 wj = the tree over the (1 + wi) x (1 + wj) cells whose low corner is (row = z cell, column = x cell)
     // section 8(f3): rectangles / triangles and FlipNormals / Translate / RotateY instances (hitable.clj:269-511, 548-581)
     int has_ext;             // any primitive kind > 2, any instance wrapper, any flip
@@ -1107,15 +1108,22 @@ __device__ inline float bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, f
     const float kNoSplit = __builtin_inff();
     float t_split = kNoSplit;
     const int G = sc.grid_n;
-    const float bx0 = sc.grid_box[0], by0 = sc.grid_box[1], bz0 = sc.grid_box[2], bx1 = sc.grid_box[3], by1 = sc.grid_box[4], bz1 = sc.grid_box[5];
-    // entry plane of an axis = its lo plane for a ray travelling up that axis (shx == 0), else its hi plane; constants as in the node test
-    const float tn = fmaxf(fmaxf(fmaxf(fmaf(r.shx ? bx1 : bx0, r.ixy.x, r.cex), fmaf(r.shy ? by1 : by0, r.ixy.y, r.cey)), fmaxf(fmaf(r.shz ? bz1 : bz0, r.izz.x, r.cez), r.tmin_lo)), t_from);
-    const float tf = fminf(fminf(fmaf(r.shx ? bx0 : bx1, r.ixy.x, r.cxx), fmaf(r.shy ? by0 : by1, r.ixy.y, r.cxy)), fminf(fmaf(r.shz ? bz0 : bz1, r.izz.x, r.cxz), best_hi));
+    // The slab test of a node visit: per axis the {lo, hi} half pair is rotated by the ray's direction sign (entry plane first) and v_fma_mix_f32 gives
+    // entry and exit distances with the ray's own conservative constants -- 3 + 6 instructions per box, where selecting float planes by sign took 18.
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    auto box_range = [&](const unsigned w0, const unsigned w1, const unsigned w2, float far_hi, float &tn_, float &tf_) {
+        const h2 hx = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(w0, w0, r.shx)), hy = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(w1, w1, r.shy)),
+                 hz = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(w2, w2, r.shz));
+        tn_ = fmaxf(fmaxf(fmaf((float)hx.x, r.ixy.x, r.cex), fmaf((float)hy.x, r.ixy.y, r.cey)), fmaxf(fmaf((float)hz.x, r.izz.x, r.cez), r.tmin_lo));
+        tf_ = fminf(fminf(fmaf((float)hx.y, r.ixy.x, r.cxx), fmaf((float)hy.y, r.ixy.y, r.cxy)), fminf(fmaf((float)hz.y, r.izz.x, r.cxz), far_hi));
+    };
+    float tn, tf;
+    box_range(sc.grid_box_h[0], sc.grid_box_h[1], sc.grid_box_h[2], best_hi, tn, tf);
+    tn = fmaxf(tn, t_from);
     int tall = first ? sc.grid_tall : RTMI_BVH_EMPTY;
     if (tall != RTMI_BVH_EMPTY) { // (wave-uniform) the tall primitives' tree: only if the ray meets their box within its range
-        const float ux0 = sc.grid_tall_box[0], uy0 = sc.grid_tall_box[1], uz0 = sc.grid_tall_box[2], ux1 = sc.grid_tall_box[3], uy1 = sc.grid_tall_box[4], uz1 = sc.grid_tall_box[5];
-        const float un = fmaxf(fmaxf(fmaf(r.shx ? ux1 : ux0, r.ixy.x, r.cex), fmaf(r.shy ? uy1 : uy0, r.ixy.y, r.cey)), fmaxf(fmaf(r.shz ? uz1 : uz0, r.izz.x, r.cez), r.tmin_lo));
-        const float uf = fminf(fminf(fmaf(r.shx ? ux0 : ux1, r.ixy.x, r.cxx), fmaf(r.shy ? uy0 : uy1, r.ixy.y, r.cxy)), fminf(fmaf(r.shz ? uz0 : uz1, r.izz.x, r.cxz), best_hi));
+        float un, uf;
+        box_range(sc.grid_tall_box_h[0], sc.grid_tall_box_h[1], sc.grid_tall_box_h[2], best_hi, un, uf);
         tall = un > uf ? RTMI_BVH_EMPTY : tall; // (a NaN keeps the tree)
     }
     constexpr int stride = RTMI_BVH_STRIDE;
@@ -1134,8 +1142,8 @@ __device__ inline float bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, f
         auto rect = [&]() { // the cells the rectangle of the range's two end points touches
             const float qx = fmaf(p1x, ax, bx), qz = fmaf(p1z, az, bz);
             const float fx0 = fminf(sx, qx) - ex, fx1 = fmaxf(sx, qx) + ex, fz0 = fminf(sz, qz) - ez, fz1 = fmaxf(sz, qz) + ez;
-            i0 = (int)fminf(fmaxf(floorf(fx0), 0.0f), gmax); i1 = (int)fminf(fmaxf(floorf(fx1), 0.0f), gmax);
-            j0 = (int)fminf(fmaxf(floorf(fz0), 0.0f), gmax); j1 = (int)fminf(fmaxf(floorf(fz1), 0.0f), gmax);
+            i0 = (int)__builtin_amdgcn_fmed3f(floorf(fx0), 0.0f, gmax); i1 = (int)__builtin_amdgcn_fmed3f(floorf(fx1), 0.0f, gmax); // (med3 of a NaN: the smaller bound)
+            j0 = (int)__builtin_amdgcn_fmed3f(floorf(fz0), 0.0f, gmax); j1 = (int)__builtin_amdgcn_fmed3f(floorf(fz1), 0.0f, gmax);
             wi = i1 - i0; wj = j1 - j0;
             return wi <= 1 && wj <= 1 && (wi + 1) * (wj + 1) <= sc.grid_kmax; // (a NaN: false)
         };
@@ -1144,8 +1152,8 @@ __device__ inline float bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, f
             // the first piece: as far as the range stays inside the two cells per axis that hold its start (and the start's own margin), less 2^-8 of
             // a cell for the rounding of this very computation -- the rectangle of the piece is then taken from its end points like any other
             const float gx = dx * ax, gz = dz * az; // cells per unit of t
-            const float lx = gx >= 0.0f ? fminf(fmaxf(floorf(sx - ex), 0.0f), gmax) + (2.0f - 1.0f / 256.0f) - ex : fminf(fmaxf(floorf(sx + ex), 0.0f), gmax) - (1.0f - 1.0f / 256.0f) + ex;
-            const float lz = gz >= 0.0f ? fminf(fmaxf(floorf(sz - ez), 0.0f), gmax) + (2.0f - 1.0f / 256.0f) - ez : fminf(fmaxf(floorf(sz + ez), 0.0f), gmax) - (1.0f - 1.0f / 256.0f) + ez;
+            const float lx = gx >= 0.0f ? __builtin_amdgcn_fmed3f(floorf(sx - ex), 0.0f, gmax) + (2.0f - 1.0f / 256.0f) - ex : __builtin_amdgcn_fmed3f(floorf(sx + ex), 0.0f, gmax) - (1.0f - 1.0f / 256.0f) + ex;
+            const float lz = gz >= 0.0f ? __builtin_amdgcn_fmed3f(floorf(sz - ez), 0.0f, gmax) + (2.0f - 1.0f / 256.0f) - ez : __builtin_amdgcn_fmed3f(floorf(sz + ez), 0.0f, gmax) - (1.0f - 1.0f / 256.0f) + ez;
             const float ts = tn + fminf((lx - sx) * __builtin_amdgcn_rcpf(gx), (lz - sz) * __builtin_amdgcn_rcpf(gz));
             p1x = fmaf(ts, dx, ox); p1z = fmaf(ts, dz, oz);
             if (!(ts > tn && ts < tf && sc.grid_kmax >= 4 && rect())) return kNoSplit; // (cannot happen for margins far below a cell; if it does: the whole tree, from its root)
