@@ -96,7 +96,7 @@ int rtmi_version(void);
 int rtmi_init(int device, uint32_t flags, rtmi_ctx **out_ctx);
 int rtmi_shutdown(rtmi_ctx *ctx);
 /* knobs: "accel" (RTMI_ACCEL_*; default RTMI_ACCEL_BVH -- bit-identical to the flat scan), "count_traversal" (0/1: the next
- * renders run the counting instantiation of the BVH kernel, see rtmi_last_traversal_counters), "suspend_lanes" (0..64, default 12: the
+ * renders run the counting instantiation of the BVH kernel, see rtmi_last_traversal_counters), "suspend_lanes" (0..64, default 8: the
  * BVH traversal of a wave stops descending / hands the wave back when fewer lanes than this are still descending / in the tree, and the
  * parked lanes resume in the next trip; 0 = the plain loop; the image does not depend on it), "flat_below" (default 24: a scene of rectangles /
  * triangles / instances / media / f4 textures with fewer primitives than this renders through the flat scan even under RTMI_ACCEL_BVH -- same image, a

@@ -695,7 +695,7 @@ struct rtmi_ctx {
     int last_reduce_launches = 0;
     int count_traversal = 0;      // option "count_traversal": run the COUNT instantiation of the BVH kernels
     int flat_below = 24;          // option "flat_below": mixed-kind scenes with fewer primitives answer accel = BVH with the flat scan (same image; 3 - 10 % faster there)
-    int suspend_lanes = 12;       // option "suspend_lanes": threshold of the time-sliced BVH traversal (0 = plain while-while loop); 8 .. 16 within 0.5 %
+    int suspend_lanes = 8;        // option "suspend_lanes": threshold of the time-sliced BVH traversal (0 = plain while-while loop); 6 .. 12 within 0.4 % (C3 69.3 / 69.2 / 69.5 ms at 6 / 10 / 12; 18: 70.7, 24: 73.6)
     hipStream_t last_stream = nullptr; // stream of the most recent render (rtmi_last_traversal_counters synchronises on it)
     long long tile_valid_pixels = 0;
     // timing
