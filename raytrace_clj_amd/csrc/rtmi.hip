@@ -1221,7 +1221,7 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
         }
     }
     // ---- entry grid: a BVH per x-z cell over the primitives whose boxes overlap the cell (DevScene::grid_*) -------------------------------------
-    d.grid_n = 0; d.grid_tall = RTMI_BVH_EMPTY; d.grid_kmax = 4;
+    d.grid_n = 0; d.grid_tall = RTMI_BVH_EMPTY; d.grid_kmax = 4; d.grid_walk = 0;
     grid_cells.clear();
     const char *grid_env = std::getenv("RTMI_GRID"); // "0": off; "n": n x n cells (experiments)
     if (want_grid && d.bvh_root >= 0 && !(grid_env && grid_env[0] == '0') && B.items.size() >= 256) {
@@ -1298,6 +1298,8 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
             } else {
                 d.grid_n = G;
                 if (const char *e = std::getenv("RTMI_GRID_KMAX")) d.grid_kmax = std::max(1, std::min(4, std::atoi(e)));
+                d.grid_walk = d.grid_kmax >= 4;
+                if (const char *e = std::getenv("RTMI_GRID_WALK")) d.grid_walk = d.grid_walk && e[0] != '0'; // (tests: the same grid without the piecewise walk)
                 d.grid_lo_x = (float)lb.lo[0]; d.grid_lo_z = (float)lb.lo[2];
                 d.grid_inv_x = (float)(1.0 / csx); d.grid_inv_z = (float)(1.0 / csz);
                 for (int k = 0; k < 3; ++k) { d.grid_box[k] = f_down(lb.lo[k] - B.delta - eps); d.grid_box[3 + k] = f_up(lb.hi[k] + B.delta + eps); }

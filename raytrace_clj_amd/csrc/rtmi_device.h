@@ -44,7 +44,8 @@ struct DevScene {
     // few primitives much taller than the rest form one more small tree.  A ray whose clipped segment stays within grid_kmax cells starts
     // at those cells' roots instead of descending from the root of the whole tree (half of a traversal's node visits only locate the ray).
     int grid_n;              // 0: no grid
-    int grid_kmax;           // rays touching more cells than this take the whole tree
+    int grid_kmax;           // a start may touch at most this many cells (experiments; 4 = up to 2 x 2)
+    int grid_walk;           // 1: a segment touching more cells is walked in pieces (RTMI_GRID_CHUNK); 0: it takes the whole tree, from its root (RTMI_GRID_WALK=0, or grid_kmax < 4)
     int grid_tall;           // root code of the tall primitives' tree (RTMI_BVH_EMPTY: none)
     float grid_lo_x, grid_lo_z, grid_inv_x, grid_inv_z; // cell index = floor((p - lo) * inv)
     float grid_box[6];       // lo.xyz hi.xyz of the layer primitives' boxes (rounded outward like every node box): a ray's t range inside it
@@ -1156,7 +1157,7 @@ __device__ inline float bvh_grid_entry(SceneRef sc, const BvhRay &r, float ox, f
             const float lz = gz >= 0.0f ? __builtin_amdgcn_fmed3f(floorf(sz - ez), 0.0f, gmax) + (2.0f - 1.0f / 256.0f) - ez : __builtin_amdgcn_fmed3f(floorf(sz + ez), 0.0f, gmax) - (1.0f - 1.0f / 256.0f) + ez;
             const float ts = tn + fminf((lx - sx) * __builtin_amdgcn_rcpf(gx), (lz - sz) * __builtin_amdgcn_rcpf(gz));
             p1x = fmaf(ts, dx, ox); p1z = fmaf(ts, dz, oz);
-            if (!(ts > tn && ts < tf && sc.grid_kmax >= 4 && rect())) return kNoSplit; // (cannot happen for margins far below a cell; if it does: the whole tree, from its root)
+            if (!(ts > tn && ts < tf && sc.grid_walk && rect())) return kNoSplit; // (cannot happen for margins far below a cell; if it does: the whole tree, from its root)
             t_split = ts;
 #else
             return kNoSplit; // the whole tree, from its root

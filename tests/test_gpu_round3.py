@@ -325,7 +325,9 @@ def test_entry_grid_is_bit_identical_to_the_flat_scan(monkeypatch):
     cells starts its traversal there.  Whatever the grid's shape (RTMI_GRID = cells per side, RTMI_GRID_KMAX = cells a ray may touch), hits
     must equal the exact Hitlist scan's bit for bit -- on grazing rays, rays along cell borders, rays leaving sphere surfaces, silhouette rays --
     and so must whole renders and their counters, in both precisions and with moving / tall / overlapping spheres; and the grid must actually
-    shorten traversals (node visits per segment), or it is not being used."""
+    shorten traversals (node visits per segment), or it is not being used.  Segments that touch more than 2 x 2 cells are walked in pieces (the probes
+    walk them in a loop, the render kernel parks the lane between pieces): the same grids with RTMI_GRID_WALK=0 send them to the root of the whole tree
+    instead -- same bits, more node visits."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_gpu_parity import grazing_rays, tangent_rays, random_rays, layer_scene
     def sweeps():
@@ -355,10 +357,11 @@ def test_entry_grid_is_bit_identical_to_the_flat_scan(monkeypatch):
         ds.close(); ctx.close()
         assert (ref["f64"][0][:, 0] == 1).mean() > 0.2, "the probe rays must hit things"
         visits = {}
-        for spec in ("0:4", "1:4", "5:1", "23:2", "64:4"):
-            g, k = spec.split(":")
+        for spec in ("0:4", "1:4", "1:4:nowalk", "5:1", "23:2", "64:4", "40:4", "40:4:nowalk"):
+            g, k = spec.split(":")[:2]
             monkeypatch.setenv("RTMI_GRID", g)
             monkeypatch.setenv("RTMI_GRID_KMAX", k)
+            monkeypatch.setenv("RTMI_GRID_WALK", "0" if spec.endswith("nowalk") else "1")  # long segments: walked in pieces of 2 x 2 cells / from the root of the whole tree
             ctx = core.Context(0)
             ds = core.DeviceScene(flat, ctx=ctx)  # the grid is built with the scene
             for prec in ("f64", "f32"):
@@ -376,6 +379,7 @@ def test_entry_grid_is_bit_identical_to_the_flat_scan(monkeypatch):
             ds.close(); ctx.close()
         if expect_grid:
             assert visits["1:4"] < 0.8 * visits["0:4"], (name, visits)
+            assert visits["1:4"] < 0.97 * visits["1:4:nowalk"] and visits["40:4"] <= visits["40:4:nowalk"], (name, visits)  # the walk is taken, and it is shorter (40 cells per side: declined for the small scenes)
         else:
             assert visits["1:4"] == visits["0:4"] == visits["64:4"], (name, visits)  # declined: the whole tree, whatever the requested shape
 
