@@ -1241,7 +1241,11 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
         // ~3.5 primitives per cell (C3: 53 x 53 cells, C2: 12 x 12).  Before long segments were walked in pieces (RTMI_GRID_CHUNK) ~10 per cell was best (C3, 16 .. 48
         // cells per side: 84.1 / 82.3 / 83.3 ms: a finer grid sent more rays to the root of the whole tree); with the walk 32 / 40 / 48 / 56 / 64 / 72 cells: 77.2 / 76.2 /
         // 76.4 / 76.1 / 76.7 / 78.5 ms, C2 7 / 10 / 14 / 20 cells: 3.39 / 3.37 / 3.33 / 3.49 ms
-        int G = (int)std::lround(std::sqrt((double)layer.size() / 3.5));
+        // ... and cells no smaller than ~4.5 x the layer's height: a ray crosses the layer over a horizontal distance of height / tan(elevation), so a
+        // taller layer (the moving cover scene: its spheres sweep up to 0.5 upwards, the layer is 0.9 instead of 0.4 high) at the same cell size means more
+        // cells per segment, i.e. more pieces (C2 moving, 6 / 8 / 10 / 12 / 16 cells per side: 3.55 / 3.60 / 3.68 / 3.75 / 4.01 ms; for the static scenes both
+        // rules give the same cell)
+        int G = (int)std::lround(std::min(std::sqrt((double)layer.size() / 3.5), std::min(ex, ez) / (4.5 * std::max(ey, 1e-300))));
         if (grid_env && std::atoi(grid_env) > 1) G = std::atoi(grid_env);
         G = std::max(2, std::min(G, 96));
         // worth it for a flat, wide layer of many primitives with few tall outliers
@@ -1687,6 +1691,9 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     std::vector<int> grid_cells;
     const std::vector<float> bvh_nodes = build_bvh(d, n_world, pk.data(), wbox, bounded, cam, !has_ext, grid_cells);
     s->bvh_node_count = (int)(bvh_nodes.size() / (d.bvh_node16 ? 8 : 16));
+    if (std::getenv("RTMI_DEBUG"))
+        fprintf(stderr, "[rtmi] tree: %d node records of %d bytes (%.2f MB), %d big primitives; entry grid %d x %d cells, %zu rectangle trees\n", s->bvh_node_count,
+                d.bvh_node16 ? 32 : 64, s->bvh_node_count * (d.bvh_node16 ? 32.0 : 64.0) / 1e6, d.n_big, d.grid_n, d.grid_n, grid_cells.size());
     if (!rc) rc = upload(s, bvh_nodes, &d.bvh_nodes);
     if (!rc) rc = upload(s, grid_cells, &d.grid_cells);
     std::vector<int> moving_all;
