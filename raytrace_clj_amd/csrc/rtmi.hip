@@ -1247,7 +1247,7 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
         // rules give the same cell)
         int G = (int)std::lround(std::min(std::sqrt((double)layer.size() / 3.5), std::min(ex, ez) / (4.5 * std::max(ey, 1e-300))));
         if (grid_env && std::atoi(grid_env) > 1) G = std::atoi(grid_env);
-        G = std::max(2, std::min(G, 96));
+        G = std::max(2, std::min(G, 256)); // (90 000 spheres: 160 x 160 cells)
         // worth it for a flat, wide layer of many primitives with few tall outliers
         if (layer.size() >= 256 && tall.size() * 20 <= n_items && ex > 0 && ez > 0 && ey < 0.25 * std::min(ex, ez)) {
             const double eps = 4.0 * B.delta; // cells claim the primitives whose (already inflated) boxes come this close; the device grows a ray's cell rectangle by its own position error
