@@ -135,13 +135,14 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
         // that medium with the t-max the list would hand it -- the closest hit so far --, the surfaces up to the next medium, and so on.  (These
         // scenes run the instantiation without time-slicing: media_seq and SLICED never meet.)
         int prev = 0;
+        MediumChord chord; chord.idx = -1; chord.ok = false; chord.t1 = chord.t2 = chord.mag = 0.0;
         for (int k = 0; k <= sc.n_media; ++k) {
             const int m = k < sc.n_media ? sc.media_idx[k] : sc.n_all;
             if (m > prev) {
                 if (bvh) scan_bvh_ext<false, COUNT>(sc, stack, P, a, tmin, H, nullptr, false, 0, cnt, prev, m);
                 else scan_all_cull_ext(sc, P, a, tmin, H, prev, m);
             }
-            if (k < sc.n_media) ext_medium_test(sc, m, P, tmin, H.any ? H.t : tmax, H, COUNT ? cnt : nullptr);
+            if (k < sc.n_media) ext_medium_test(sc, m, P, tmin, H.any ? H.t : tmax, H, chord, COUNT ? cnt : nullptr);
             prev = m + 1;
         }
         best_i = ext_winner(H);
@@ -156,7 +157,10 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
         } else scan_bvh_ext<false, COUNT>(sc, stack, P, a, tmin, H, nullptr, false, 0, cnt);
     } else scan_all_cull_ext(sc, P, a, tmin, H);
     // media: after the surfaces, in primitive-index order = the order the reference's descent calls their hit? (and draws)
-    for (int k = 0; k < sc.n_media; ++k) ext_medium_test(sc, sc.media_idx[k], P, tmin, tmax, H, COUNT ? cnt : nullptr);
+    RTMI_PH(PH_BVH_POST)
+    MediumChord chord; chord.idx = -1; chord.ok = false; chord.t1 = chord.t2 = chord.mag = 0.0;
+    for (int k = 0; k < sc.n_media; ++k) ext_medium_test(sc, sc.media_idx[k], P, tmin, tmax, H, chord, COUNT ? cnt : nullptr);
+    RTMI_PH(PH_LOOP) // (diagnostic build: the media are booked on the otherwise unused first phase)
     best_i = ext_winner(H);
     if (best_i >= 0) best_t = H.t;
 }

@@ -1415,11 +1415,15 @@ __device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P
 // segment between them clipped to [t-min, t-max]; then ONE draw of the path's stream: hit-distance = -(log xi)/density
 // against the length of the segment decides whether (where) the ray scatters inside.  t-min/t-max are the caller's
 // un-narrowed interval, as in the reference's bvh-node descent (hitable.clj:99-105).
-__device__ inline void ext_medium_test(SceneRef sc, int idx, Path<double> &P, double tmin, double tmax, ExtHit &H, unsigned *cnt = nullptr) {
+// The boundary part is a function of (medium, ray) alone -- no draw, no t-min / t-max --, so a medium the reference asks twice in a row (make-bvh stores a lone
+// item as bvh-node(L, L) and hit? evaluates both children, hitable.clj:113-114: make-final's haze is media call 2 AND 3 of every ray) computes it once:
+// MediumChord caches it for the next call with the same index (the index sequence is wave-uniform).
+struct MediumChord { int idx; bool ok; double t1, t2, mag; };
+__device__ inline void ext_medium_chord(SceneRef sc, int idx, const Path<double> &P, MediumChord &C, unsigned *cnt = nullptr) {
     const double FMAX = 3.4028234663852886e38;
     const size_t gi = (size_t)idx * 12; // idx comes from media_idx: wave-uniform
-    const double density = ext_ld<true>(sc.exact12, gi);
     const int first = (int)ext_ld<true>(sc.exact12, gi + 1), count = (int)ext_ld<true>(sc.exact12, gi + 2);
+    C.idx = idx; C.ok = false; C.t1 = C.t2 = C.mag = 0.0;
     ExtHit h1 = {FMAX, 0x7fffffff, -1, false};
     for (int k = 0; k < count; ++k) ext_prim_test<true>(sc, first + k, P, -FMAX, h1); // idx (a medium of media_idx) is wave-uniform
     if (cnt) cnt[1] += (unsigned)count; // exact tests of the boundary's primitives
@@ -1428,17 +1432,23 @@ __device__ inline void ext_medium_test(SceneRef sc, int idx, Path<double> &P, do
     ExtHit h2 = {FMAX, 0x7fffffff, -1, false};
     for (int k = 0; k < count; ++k) ext_prim_test<true>(sc, first + k, P, h1.t + 0.0001, h2);
     if (!h2.any) return;
-    double t1 = h1.t, t2 = h2.t;
+    const int4 info = ext_ld_info<true>(sc.ext_info, idx);
+    const LocalRay r = ext_local_ray<true>(sc, info.z, info.w, P);
+    C.mag = rt_sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
+    C.t1 = h1.t; C.t2 = h2.t; C.ok = true;
+}
+__device__ inline void ext_medium_test(SceneRef sc, int idx, Path<double> &P, double tmin, double tmax, ExtHit &H, MediumChord &C, unsigned *cnt = nullptr) {
+    if (C.idx != idx) ext_medium_chord(sc, idx, P, C, cnt); // (wave-uniform)
+    if (!C.ok) return;
+    double t1 = C.t1, t2 = C.t2;
     if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
     if (!(t1 < t2)) return;
     if (t1 < 0.0) t1 = 0.0;
-    const int4 info = ext_ld_info<true>(sc.ext_info, idx);
-    const LocalRay r = ext_local_ray<true>(sc, info.z, info.w, P);
-    const double mag = rt_sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
-    const double dist_in = (t2 - t1) * mag;
+    const double density = ext_ld<true>(sc.exact12, (size_t)idx * 12);
+    const double dist_in = (t2 - t1) * C.mag;
     const double hit_distance = -(::log(next_uniform(P)) / density);
-    if (hit_distance < dist_in) ext_update(H, t1 + hit_distance / mag, idx, true);
+    if (hit_distance < dist_in) ext_update(H, t1 + hit_distance / C.mag, idx, true);
 }
 
 // the flat scan (FP32 cull + exact test) over all primitives
@@ -1479,9 +1489,11 @@ __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> 
         H.F = sw[5 * stride]; H.W = sw[6 * stride]; H.any = H.F != 0x7fffffff;
     } else {
         if (!r.ok) { if (COUNT) cnt[1] += (unsigned)sc.n_all; scan_all_cull_ext(sc, P, a, tmin, H, lo, hi); return true; }
+        RTMI_PH(PH_BVH_SETUP)
         if (COUNT) cnt[1] += (unsigned)sc.n_big;
         for (int k = 0; k < sc.n_big; ++k) if (sc.big_idx[k] >= lo && sc.big_idx[k] < hi) ext_prim_test<true>(sc, sc.big_idx[k], P, tmin, H);
         cur = bvh_cursor_at_root(sc, stack);
+        RTMI_PH(PH_BIG)
     }
     auto leaf = [&](int code) { const int idx = (~code) & 0x3fffffff; if (idx >= lo && idx < hi) ext_prim_test<false>(sc, idx, P, tmin, H); };
     auto best = [&]() { return ext_best_hi(H); };
