@@ -281,10 +281,11 @@ int rtmi_probe_rng(rtmi_ctx *ctx, int32_t precision, uint64_t key, uint64_t d0, 
 uint64_t rtmi_sample_key(uint64_t seed, uint64_t pixel, uint64_t sample);
 /* correctly-rounded device arithmetic check: out[k] = {a/b, sqrt(|a|), a*b+c unfused} */
 int rtmi_probe_arith(rtmi_ctx *ctx, int32_t n, const double *abc, double *out);
-/* the path's own FP64 helpers, one thread per triple (a, b, c):  out[8k..] = { sqrt(a) (fast path when the whole wave's arguments are
+/* the path's own FP64 helpers, one thread per triple (a, b, c):  out[9k..] = { sqrt(a) (fast path when the whole wave's arguments are
  * finite and >= 2^-767, libm otherwise), atan2(a, b), asin(a), u and v of get-sphere-uv for the unit normal (a, b, c) (hitable.clj:128-139),
  * a / b through the per-ray reciprocal of the sphere roots (t-min / t-max decide with b whether the wave takes it), a / (2 pi) by the
- * constant-divisor form, 1.0 if the wave took the reciprocal path else 0.0 } */
+ * constant-divisor form, 1.0 if the lane took the reciprocal path else 0.0, the traversal's float bound of a closest hit at t = c: a float >= c
+ * within two ulps (FLT_MAX beyond the float range) } */
 int rtmi_probe_math(rtmi_ctx *ctx, int32_t n, const double *abc, double tmin, double tmax, double *out);
 
 #ifdef __cplusplus

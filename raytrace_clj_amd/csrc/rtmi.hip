@@ -1378,7 +1378,7 @@ int check_render_args(rtmi_scene *s, int nx, int ny, int ns, int depth, int prec
 // ---- library / context -------------------------------------------------------------------------------
 RTMI_EXPORT const char *rtmi_last_error(void) { return g_err.c_str(); }
 RTMI_EXPORT const char *rtmi_backend_name(void) { return "hip-gfx950"; }
-RTMI_EXPORT int rtmi_version(void) { return 202; }
+RTMI_EXPORT int rtmi_version(void) { return 203; } // 203: rtmi_probe_math writes 9 values per triple (float_above)
 RTMI_EXPORT uint64_t rtmi_sample_key(uint64_t seed, uint64_t pixel, uint64_t sample) { return sample_key(seed, pixel, sample); }
 
 RTMI_EXPORT int rtmi_init(int device, uint32_t flags, rtmi_ctx **out_ctx) {
@@ -2513,7 +2513,7 @@ __global__ void probe_math_kernel(int n, const double *abc, double tmin, double 
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const double a = abc[3 * k], b = abc[3 * k + 1], c = abc[3 * k + 2];
-    double *o = out + (size_t)k * 8;
+    double *o = out + (size_t)k * 9;
     o[0] = rt_sqrt(a);
     const TrigTable K = trig_table();
     o[1] = rt_atan2(a, b, K);
@@ -2523,6 +2523,7 @@ __global__ void probe_math_kernel(int n, const double *abc, double tmin, double 
     o[5] = q(a);
     o[6] = div_const(a, K[29], K[27]);
     o[7] = (double)q.fast;
+    o[8] = (double)float_above(c); // the traversal's float bound of the closest hit so far: a float >= c, within two ulps
 }
 
 RTMI_EXPORT int rtmi_probe_arith(rtmi_ctx *c, int32_t n, const double *abc, double *out) {
@@ -2546,11 +2547,11 @@ RTMI_EXPORT int rtmi_probe_math(rtmi_ctx *c, int32_t n, const double *abc, doubl
     HIP_TRY(hipSetDevice(c->device));
     Tmp tmp;
     double *d_in = (double *)tmp.up(abc, (size_t)n * 3 * sizeof(double));
-    double *d_out = (double *)tmp.alloc((size_t)n * 8 * sizeof(double));
+    double *d_out = (double *)tmp.alloc((size_t)n * 9 * sizeof(double));
     if (!d_in || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
     const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(probe_math_kernel, dim3(grid), dim3(kBlock), 0, c->stream, n, d_in, tmin, tmax, d_out);
     PROBE_EPILOGUE()
-    HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 8 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost));
     return RTMI_OK;
 }

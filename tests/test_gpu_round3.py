@@ -498,3 +498,26 @@ def test_small_mixed_scenes_are_scanned_even_when_the_tree_is_asked_for(monkeypa
     with pytest.raises(core.RtmiError):
         ctx.set_option("flat_below", -1)
     ctx.close()
+
+
+# ---- the traversal's float bound of the closest hit (rtmi_device.h: float_above) -----------------------------------------------------------------------------
+def test_float_bound_of_the_closest_hit_is_a_bound():
+    """the BVH traversal prunes boxes against a FLOAT upper bound of the FP64 closest hit, refreshed after every exact-test phase; since round 3 it
+    is RN(t)(1 + 2^-23) + 2^-120 (three instructions) instead of the exact next float above t: it must never be below t, whatever t -- positive,
+    negative (probes with t-min < 0), denormal, a float already, just above / below a float, huge -- and it should stay within two float ulps"""
+    rng = np.random.default_rng(3)
+    f = rng.standard_normal(20000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 20000).astype(np.float32)
+    f = f[np.isfinite(f)]
+    exact = f.astype(np.float64)
+    t = np.concatenate([exact, np.nextafter(exact, np.inf), np.nextafter(exact, -np.inf), exact * (1 + 2.0 ** -30), exact * (1 - 2.0 ** -30),
+                        10.0 ** rng.uniform(-300, 300, 20000) * rng.choice([-1.0, 1.0], 20000), [0.0, -0.0, 5e-324, -5e-324, 1e-46, 1.4e-45, 3.4028234663852886e38,
+                                                                                                 3.4028235e38, 1e39, -1e39, 1e300, 0.001, 1.0]])
+    out = core.probe_math(np.stack([np.ones_like(t), np.ones_like(t), t], axis=1))[:, 8]
+    fmax = 3.4028234663852886e38
+    assert np.all(np.isfinite(out)) and np.all(out == out.astype(np.float32).astype(np.float64)), "a float"
+    inside = np.abs(t) < fmax
+    assert np.all(out[inside] >= t[inside]), "never below t"
+    assert np.all(out[t >= fmax] == fmax), "beyond the float range: FLT_MAX (the closest hit so far never exceeds the caller's t-max = Float/MAX_VALUE)"
+    normal = inside & (np.abs(t) > 1e-25)  # (below, the absolute term 2^-120 that covers the denormal range shows)
+    up = np.nextafter(np.nextafter(np.nextafter(t[normal].astype(np.float32), np.float32(np.inf)), np.float32(np.inf)), np.float32(np.inf)).astype(np.float64)
+    assert np.all(out[normal] <= up), "within a few float ulps"
