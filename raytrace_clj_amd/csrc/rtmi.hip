@@ -1717,7 +1717,9 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
       // per coordinate: a gradient whose corner colours do not vary along u never reads u --, ImageMap, through Checkerboard / FlipTexture
       // children); Constant, Checkerboard itself and the Perlin family read p only
         std::vector<char> uses((size_t)std::max(n_tex, 1), 0); // bit 0: reads u, bit 1: reads v
-        for (int pass = 0; pass <= n_tex; ++pass) // children may come after their parents: iterate to the fixed point
+        bool changed = true;
+        for (int pass = 0; pass <= n_tex && changed; ++pass) { // children may come after their parents: iterate to the fixed point (a pass that changes nothing ends it:
+            changed = false;                                  // one texture per sphere made the unconditional n_tex passes 5.8 of the 6.4 s a 90 000-sphere scene took to create)
             for (int t = 0; t < n_tex; ++t) {
                 const int k = tex_kind[t];
                 char u = k == RTMI_TEX_IMAGE ? 3 : 0;
@@ -1735,8 +1737,9 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
                         const int ch = tex_child[2 * (size_t)t + c];
                         if (ch >= 0 && ch < n_tex) u |= uses[(size_t)ch];
                     }
-                uses[(size_t)t] = u;
+                if (uses[(size_t)t] != u) { uses[(size_t)t] = u; changed = true; }
             }
+        }
         std::vector<int> pk_dev(pk);
         for (int i = 0; i < n_prims; ++i)
             if (pk[(size_t)i] == RTMI_PRIM_UVSPHERE) {
