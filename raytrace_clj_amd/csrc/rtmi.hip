@@ -2183,9 +2183,12 @@ RTMI_EXPORT int rtmi_render_multi_device(int32_t n, rtmi_scene *const *scenes, i
     HIP_BAIL(hipEventRecord(c0->ev_g0, c0->stream));
     if (use_rccl) {
         ncclResult_t e = g_rccl.GroupStart();
-        for (int r = 0; r < n && e == ncclSuccess; ++r)
+        for (int r = 0; r < n && e == ncclSuccess; ++r) {
+            (void)hipSetDevice(scenes[r]->ctx->device); // (a communicator knows its device; older RCCLs still want it current for calls inside a group)
             e = g_rccl.Gather(recs[(size_t)r], r == 0 ? gathered : nullptr, rec, ncclUint64, 0, (*comms)[(size_t)r], scenes[r]->ctx->stream);
+        }
         const ncclResult_t e2 = g_rccl.GroupEnd();
+        (void)hipSetDevice(c0->device);
         if (e == ncclSuccess) e = e2;
         if (e != ncclSuccess) { // this communicator set is not trusted again: later calls gather by copies
             const int code = fail(RTMI_E_DEVICE, "ncclGather: %s", g_rccl.GetErrorString(e));
