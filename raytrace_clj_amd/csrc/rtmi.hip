@@ -58,6 +58,9 @@ __device__ inline unsigned long long real_now() { unsigned long long t; asm vola
 #ifndef RTMI_MIN_WAVES
 #define RTMI_MIN_WAVES 4
 #endif
+#ifndef RTMI_EXT_MIN_WAVES
+#define RTMI_EXT_MIN_WAVES RTMI_MIN_WAVES // waves per SIMD the mixed-kind (EXT) instantiations are compiled for
+#endif
 
 struct TraceParams {
     int nx, ny, depth;
@@ -76,12 +79,17 @@ struct TraceParams {
     int suspend_lanes;     // time-sliced traversal: hand the wave back when fewer lanes than this are still in the tree (0: never)
     int rx0, ry0, rx1, ry1; // output region (row 0 = top): pixels outside it are not traced (whole frame: 0, 0, nx, ny)
     u64 *trav;             // COUNT instantiations: [0] += AABB slab tests (metrics aabb.intersection.total, hitable.clj:39), [1] += exact primitive tests
+    int susp_off;          // mixed-kind (EXT) BVH kernels: word offset of the parked cursors in LDS = stack levels of THIS scene's tree x RTMI_BVH_STRIDE
+    int stash_off;         // mixed-kind kernels: word offset of the camera-ray stash in LDS (behind the stack and the parked cursors; 0 for the scan)
 };
 #ifndef RTMI_QUEUE_BLOCK
 #define RTMI_QUEUE_BLOCK 256
 #endif
 #ifndef RTMI_EXT_NO_STASH
 #define RTMI_EXT_NO_STASH 0 // 1: the EXT (f3 / f4) instantiations refill per trip (17 VGPRs fewer)
+#endif
+#ifndef RTMI_EXT_LDS_STASH
+#define RTMI_EXT_LDS_STASH 1 // the mixed-kind instantiations keep the camera-ray stash in LDS (11 or 17 words per entry), not in 17 VGPRs: they stand at the 128-VGPR limit of 4 waves per SIMD
 #endif
 #ifndef RTMI_STASH
 #define RTMI_STASH 1 // camera rays generated 64 at a time at full wave width into a register stash (0: per trip, for the dead lanes only)
@@ -124,7 +132,7 @@ __device__ inline void scan_cull_dispatch(SceneRef sc, const Path<float> &P, flo
 // MSEQ: the instantiations for RTMI_MEDIA_HITLIST worlds (their own kernels: the plain mixed-kind kernels keep their registers)
 template <bool SLICED = false, bool COUNT = false, bool MSEQ = false>
 __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<double> &P, bool active, double tmin, double tmax, double &best_t, int &best_i,
-                                     bool *mid = nullptr, int min_lanes = 0, unsigned *cnt = nullptr) {
+                                     bool *mid = nullptr, int min_lanes = 0, unsigned *cnt = nullptr, int susp_off = RTMI_BVH_STACK * RTMI_BVH_STRIDE) {
     best_t = tmax; best_i = -1;
     if (!active) return;
     const double a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
@@ -151,7 +159,7 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
     }
     if (bvh) {
         if (SLICED) { // time-sliced: a suspended lane's media are evaluated (and draw) when its traversal completes, as in the plain loop
-            const bool done = scan_bvh_ext<true, COUNT>(sc, stack, P, a, tmin, H, stack + RTMI_BVH_STACK * RTMI_BVH_STRIDE, *mid, min_lanes, cnt);
+            const bool done = scan_bvh_ext<true, COUNT>(sc, stack, P, a, tmin, H, stack + susp_off, *mid, min_lanes, cnt);
             *mid = !done;
             if (!done) return;
         } else scan_bvh_ext<false, COUNT>(sc, stack, P, a, tmin, H, nullptr, false, 0, cnt);
@@ -165,14 +173,15 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
     if (best_i >= 0) best_t = H.t;
 }
 template <bool SLICED = false, bool COUNT = false, bool MSEQ = false>
-__device__ inline void intersect_ext(SceneRef, int *, bool, Path<float> &, bool, float, float tmax, float &best_t, int &best_i, bool * = nullptr, int = 0, unsigned * = nullptr) { best_t = tmax; best_i = -1; }
+__device__ inline void intersect_ext(SceneRef, int *, bool, Path<float> &, bool, float, float tmax, float &best_t, int &best_i, bool * = nullptr, int = 0, unsigned * = nullptr, int = 0) { best_t = tmax; best_i = -1; }
 
 // NOGRID: the plain (not time-sliced) RENDER kernel -- never launched on a scene with an entry grid, so it carries no code for one (the probe
 // kernels, also not time-sliced, do: they walk a long segment's pieces in a loop of their own)
 template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICED = false, bool MSEQ = false, bool NOGRID = false>
 __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, Path<R> &P,
-                                       bool active, R tmin, R tmax, R &best_t, int &best_i, unsigned *cnt = nullptr, bool *mid = nullptr, int min_lanes = 0) {
-    if (EXT) { intersect_ext<SLICED, COUNT, MSEQ>(sc, reinterpret_cast<int *>(lds), VARIANT == SCAN_BVH, P, active, tmin, tmax, best_t, best_i, mid, min_lanes, cnt); return; }
+                                       bool active, R tmin, R tmax, R &best_t, int &best_i, unsigned *cnt = nullptr, bool *mid = nullptr, int min_lanes = 0,
+                                       int susp_off = RTMI_BVH_STACK * RTMI_BVH_STRIDE) {
+    if (EXT) { intersect_ext<SLICED, COUNT, MSEQ>(sc, reinterpret_cast<int *>(lds), VARIANT == SCAN_BVH, P, active, tmin, tmax, best_t, best_i, mid, min_lanes, cnt, susp_off); return; }
     best_t = tmax;
     best_i = -1;
     const R a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
@@ -235,7 +244,7 @@ template <typename R> __device__ inline void start_sample(SceneRef sc, const Tra
 
 // SLICE: time-sliced BVH traversal (section 5.1b of DESIGN.md); the plain instantiation is kept for scenes whose tree is too small to gain
 template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICE = true, bool MSEQ = false>
-__global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
+__global__ void __launch_bounds__(kTraceBlock, EXT ? RTMI_EXT_MIN_WAVES : RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
     SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Prim4<R> *lds = reinterpret_cast<Prim4<R> *>(smem);
@@ -257,7 +266,11 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
     bool alive = false;
     bool exhausted = (total_items == 0);
     unsigned out_item = 0; // work item of the lane's path: its colour goes to samples[out_item]
-    constexpr bool STASH = RTMI_STASH && !(EXT && RTMI_EXT_NO_STASH);
+    constexpr bool LSTASH = EXT && RTMI_STASH && RTMI_EXT_LDS_STASH && !RTMI_EXT_NO_STASH;
+    constexpr bool STASH = RTMI_STASH && !(EXT && RTMI_EXT_NO_STASH) && !LSTASH;
+    // LSTASH: entry e of wave w = words lst[k * kTraceBlock + e], k = 0..5 direction, 6..7 time, 8..9 stream state, 10 work item (-1: none), 11..16 origin
+    // (only written / read when the camera's rays do not all start at one point).  Written and read by the same wave only.
+    int *const lst = reinterpret_cast<int *>(smem) + tp.stash_off + (threadIdx.x & ~63);
     R st_ox = R(0), st_oy = R(0), st_oz = R(0), st_dx = R(0), st_dy = R(0), st_dz = R(0), st_time = R(0); // the stash: one generated camera ray per lane
     u64 st_rs = 0;
     unsigned st_item = 0xffffffffu;
@@ -272,7 +285,73 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
     for (;;) {
         RTMI_PH(PH_LOOP) // loop overhead / tail
         // ---- refill dead lanes ------------------------------------------------------------------------------------------
-        if (STASH) {
+        if (LSTASH) {
+        for (;;) { // wave-uniform control flow; as the register stash below with the entries in LDS
+            const u64 dead = __ballot(!alive);
+            if (dead == 0) break;
+            if (s_head == 64u) {
+                if (exhausted) break;
+                if (w_cur == w_end) {
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(tp.queue, tp.qblock);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= total_items) { exhausted = true; break; }
+                    w_cur = base;
+                    w_end = min(base + tp.qblock, total_items);
+                }
+                const unsigned m = w_cur + (unsigned)lane;
+                w_cur += 64u;
+                const unsigned chunk = m >> 6;
+                const int l = (int)(m & 63u);
+                const int tile_local = (int)(chunk / (unsigned)tp.s_count);
+                const int s = tp.s_begin + (int)(chunk - (unsigned)tile_local * (unsigned)tp.s_count);
+                const int gtile = tp.tile_ids[tile_local];
+                const int x = (gtile % tp.tiles_x) * RTMI_TILE + (l & 7);
+                const int y = (gtile / tp.tiles_x) * RTMI_TILE + (l >> 3);
+                int item = -1;
+                if (x >= tp.rx0 && x < tp.rx1 && y >= tp.ry0 && y < tp.ry1) {
+                    Path<R> Q;
+                    start_sample<R>(sc, tp, x, tp.ny - 1 - y, s, Q); // j = ny-1-y (core.clj:105)
+                    int w0, w1;
+                    best_to_words<R>(Q.dx, w0, w1); lst[lane] = w0; lst[kTraceBlock + lane] = w1;
+                    best_to_words<R>(Q.dy, w0, w1); lst[2 * kTraceBlock + lane] = w0; lst[3 * kTraceBlock + lane] = w1;
+                    best_to_words<R>(Q.dz, w0, w1); lst[4 * kTraceBlock + lane] = w0; lst[5 * kTraceBlock + lane] = w1;
+                    best_to_words<R>(Q.time, w0, w1); lst[6 * kTraceBlock + lane] = w0; lst[7 * kTraceBlock + lane] = w1;
+                    lst[8 * kTraceBlock + lane] = (int)(unsigned)Q.rs; lst[9 * kTraceBlock + lane] = (int)(unsigned)(Q.rs >> 32);
+                    if (!sc.cam_fixed_origin) {
+                        best_to_words<R>(Q.ox, w0, w1); lst[11 * kTraceBlock + lane] = w0; lst[12 * kTraceBlock + lane] = w1;
+                        best_to_words<R>(Q.oy, w0, w1); lst[13 * kTraceBlock + lane] = w0; lst[14 * kTraceBlock + lane] = w1;
+                        best_to_words<R>(Q.oz, w0, w1); lst[15 * kTraceBlock + lane] = w0; lst[16 * kTraceBlock + lane] = w1;
+                    }
+                    item = (int)m;
+                    RTMI_PH(PH_REFILL_GEN)
+                }
+                lst[10 * kTraceBlock + lane] = item;
+                s_head = 0u;
+            }
+            const unsigned avail = 64u - s_head, nd = (unsigned)__popcll(dead);
+            const unsigned rank = (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
+            if (!alive && rank < avail) {
+                const int e = (int)(s_head + rank);
+                const int item = lst[10 * kTraceBlock + e];
+                if (item >= 0) {
+                    P.dx = best_from_words<R>(lst[e], lst[kTraceBlock + e]); P.dy = best_from_words<R>(lst[2 * kTraceBlock + e], lst[3 * kTraceBlock + e]);
+                    P.dz = best_from_words<R>(lst[4 * kTraceBlock + e], lst[5 * kTraceBlock + e]); P.time = best_from_words<R>(lst[6 * kTraceBlock + e], lst[7 * kTraceBlock + e]);
+                    P.rs = (u64)(unsigned)lst[8 * kTraceBlock + e] | ((u64)(unsigned)lst[9 * kTraceBlock + e] << 32);
+                    if (sc.cam_fixed_origin) { P.ox = (R)sc.cam[0]; P.oy = (R)sc.cam[1]; P.oz = (R)sc.cam[2]; }
+                    else {
+                        P.ox = best_from_words<R>(lst[11 * kTraceBlock + e], lst[12 * kTraceBlock + e]); P.oy = best_from_words<R>(lst[13 * kTraceBlock + e], lst[14 * kTraceBlock + e]);
+                        P.oz = best_from_words<R>(lst[15 * kTraceBlock + e], lst[16 * kTraceBlock + e]);
+                    }
+                    P.ar = P.ag = P.ab = R(1);
+                    P.depth = tp.depth;
+                    out_item = (unsigned)item;
+                    alive = true;
+                }
+            }
+            s_head += min(nd, avail);
+        }
+        } else if (STASH) {
         // Camera rays are generated 64 at a time by the WHOLE wave (key, jitter, lens disk loop, get-ray: start_sample at full
         // width) into a register stash, one entry per lane; dead lanes then pull entries across lanes (ds_bpermute): entry
         // s_head + (rank among the dead lanes).  Generating per trip for the dead lanes only ran start_sample at ~40 % width
@@ -370,7 +449,7 @@ __global__ void __launch_bounds__(kTraceBlock, RTMI_MIN_WAVES) trace_kernel(Scen
         // segments of the others.  Once the queue is empty nothing is gained by handing back early (suspend_lanes 0).
         R best_t; int best_i;
         intersect_world<R, MULTI, VARIANT, EXT, COUNT, SLICED, MSEQ, !SLICED>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i, ntrav,
-                                                                     &mid, exhausted ? 0 : tp.suspend_lanes);
+                                                                     &mid, exhausted ? 0 : tp.suspend_lanes, EXT ? tp.susp_off : RTMI_BVH_STACK * RTMI_BVH_STRIDE);
         RTMI_PH(PH_BVH_POST) // intersection: what the phases inside did not book (suspend bookkeeping, call overhead)
         if (!SLICED || __any(alive && !mid)) { // a trip in which no lane finished its segment has nothing to shade
         if (alive) {
@@ -715,6 +794,7 @@ struct rtmi_scene {
     std::vector<void *> allocs;
     int n_prims = 0, n_mats = 0, n_tex = 0;
     int bvh_node_count = 0;   // inner nodes of the device's tree
+    int bvh_depth = 0;        // deepest leaf of the device's tree(s)
     bool uses_perlin = false; // a Perlin texture is present: rtmi_scene_set_perlin must have been called before rendering
     int max_image = -1;       // highest ImageMap index: rtmi_scene_set_images must cover it
     bool have_perlin = false;
@@ -893,19 +973,31 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         const size_t bvh_lds = (size_t)(RTMI_BVH_STACK + RTMI_BVH_SUSPEND_WORDS) * kTraceBlock * sizeof(int); // stack columns + suspended cursors
         tp.suspend_lanes = c->suspend_lanes;
         if (const char *e = std::getenv("RTMI_SUSPEND_LANES")) tp.suspend_lanes = std::max(0, std::min(64, std::atoi(e)));
+        // Mixed-kind kernels: LDS = stack columns for THIS scene's tree (its depth is known: the sphere kernels use the compile-time RTMI_BVH_STACK for their
+        // immediate ds_ offsets) + the parked cursors (time-sliced instantiation) + the camera-ray stash (11 words per entry, 17 when the rays' origins differ)
+        tp.susp_off = RTMI_BVH_STACK * RTMI_BVH_STRIDE; tp.stash_off = 0;
+        constexpr bool kExtLdsStash = RTMI_STASH && RTMI_EXT_LDS_STASH && !RTMI_EXT_NO_STASH;
+        const int ext_levels = std::max(4, std::min(RTMI_BVH_STACK, s->bvh_depth + 2));
+        const int stash_words = kExtLdsStash ? (s->dev.cam_fixed_origin ? 11 : 17) : 0;
+        auto ext_lds = [&](bool bvh, int susp_words) {
+            const int levels = bvh ? ext_levels : 0;
+            tp.susp_off = levels * RTMI_BVH_STRIDE;
+            tp.stash_off = (levels + susp_words) * RTMI_BVH_STRIDE;
+            return (size_t)(levels + susp_words + stash_words) * kTraceBlock * sizeof(int);
+        };
         if (s->dev.has_ext && s->dev.media_seq) { // a Hitlist world holding media (RTMI_MEDIA_HITLIST): its own instantiations, never time-sliced
             if (variant == SCAN_BVH) {
                 kern = c->count_traversal ? trace_kernel<double, false, SCAN_BVH, true, true, false, true> : trace_kernel<double, false, SCAN_BVH, true, false, false, true>;
-                dyn_lds = (size_t)RTMI_BVH_STACK * kTraceBlock * sizeof(int);
-            } else kern = trace_kernel<double, false, SCAN_SGPR_CULL, true, false, true, true>;
+                dyn_lds = ext_lds(true, 0);
+            } else { kern = trace_kernel<double, false, SCAN_SGPR_CULL, true, false, true, true>; dyn_lds = ext_lds(false, 0); }
         } else if (s->dev.has_ext) { // section 8(f3) scenes: FP64 kernels with the mixed-kind intersectors
             if (variant == SCAN_BVH) { // a Cornell box's 20-primitive tree loses 5 % to the time-slicing machinery, make-final's 3400 gain 8 %
                 const bool slice = s->bvh_node_count >= 128 && tp.suspend_lanes > 0;
                 if (c->count_traversal) kern = slice ? trace_kernel<double, false, SCAN_BVH, true, true> : trace_kernel<double, false, SCAN_BVH, true, true, false>;
                 else kern = slice ? trace_kernel<double, false, SCAN_BVH, true> : trace_kernel<double, false, SCAN_BVH, true, false, false>;
-                dyn_lds = (size_t)(RTMI_BVH_STACK + (slice ? RTMI_BVH_SUSPEND_WORDS_EXT : 0)) * kTraceBlock * sizeof(int);
+                dyn_lds = ext_lds(true, slice ? RTMI_BVH_SUSPEND_WORDS_EXT : 0);
             }
-            else kern = trace_kernel<double, false, SCAN_SGPR_CULL, true>;
+            else { kern = trace_kernel<double, false, SCAN_SGPR_CULL, true>; dyn_lds = ext_lds(false, 0); }
         } else
         switch (variant) {
         case SCAN_BVH: // suspend_lanes = 0 or a small tree (< 128 inner nodes) selects the instantiation without the time-slicing machinery (the plain while-while loop);
@@ -1003,8 +1095,9 @@ struct BvhBuilder {
     std::vector<BvhItem> items;
     std::vector<float> nodes; // 16 floats per node
     std::vector<char> moving; // by original primitive index
+    std::vector<char> box6;   // by original primitive index: the first of six rectangles that form a Box (one leaf: RTMI_LEAF_BOX)
     double delta = 0.0;
-    int leaf_code(int idx) const { return ~(idx | (moving[(size_t)idx] ? 0x40000000 : 0)); }
+    int leaf_code(int idx) const { return ~(idx | (moving[(size_t)idx] ? 0x40000000 : 0) | (!box6.empty() && box6[(size_t)idx] ? RTMI_LEAF_BOX : 0)); }
     int sah_depth = 8, max_depth = 0;
     double min_frac = 0.0;    // experiments: RTMI_BVH_MIN_FRAC = smallest share of a node's primitives a child may get (balance)
     int sweep_max = 0;  // subtrees up to this many primitives: exact sweep SAH; above: 32 bins (build time)
@@ -1172,9 +1265,11 @@ static uint16_t half_outward(float x, bool up) {
     return b;
 }
 // fills d.bvh_* ; returns the node array to upload.  wbox[i] / bounded[i]: prim_world_box of every primitive.
+// box_first[i] != 0: primitives i .. i + 5 are the six faces of one Box (detected at scene creation) -- one leaf, unless the box is too large for the tree
 std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, const std::vector<BvhBox> &wbox, const std::vector<char> &bounded, const double *cam,
-                             bool want_grid, std::vector<int> &grid_cells) {
+                             bool want_grid, std::vector<int> &grid_cells, const std::vector<char> &box_first, int *out_depth = nullptr) {
     BvhBuilder B;
+    struct DepthOut { BvhBuilder &b; int *o; ~DepthOut() { if (o) *o = b.max_depth; } } depth_out{B, out_depth};
     std::vector<BvhItem> all;
     double obound = 0.0;
     for (int k = 0; k < 3; ++k) obound = std::max(obound, std::fabs(cam[k]));
@@ -1190,7 +1285,23 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
     }
     obound = std::min(obound, 1e15) * 1.001 + 1e-30;
     d.n_big = 0;
-    for (const BvhItem &it : all) {
+    B.box6.assign((size_t)std::max(n_prims, 1), 0);
+    for (size_t a = 0; a < all.size(); ++a) {
+        BvhItem it = all[a];
+        if (!box_first.empty() && box_first[(size_t)it.idx] && a + 5 < all.size() && all[a + 5].idx == it.idx + 5) { // a Box: the union of its six faces, if that fits the tree
+            BvhBox u = it.b;
+            bool ok = bounded[(size_t)it.idx] != 0;
+            for (int k = 1; k < 6; ++k) { box_grow(u, all[a + (size_t)k].b); ok = ok && bounded[(size_t)it.idx + (size_t)k]; }
+            const double uext = std::max(u.hi[0] - u.lo[0], std::max(u.hi[1] - u.lo[1], u.hi[2] - u.lo[2]));
+            if (ok && uext < 0.25 * obound) {
+                it.b = u;
+                for (int k = 0; k < 3; ++k) it.cen[k] = 0.5 * (u.lo[k] + u.hi[k]);
+                B.box6[(size_t)it.idx] = 1;
+                B.items.push_back(it);
+                a += 5;
+                continue;
+            }
+        }
         const double ext = std::max(it.b.hi[0] - it.b.lo[0], std::max(it.b.hi[1] - it.b.lo[1], it.b.hi[2] - it.b.lo[2]));
         if (ext >= 0.25 * obound && d.n_big < 16) d.big_idx[d.n_big++] = it.idx; // ascending index order
         else B.items.push_back(it);
@@ -1668,6 +1779,27 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
         cull_r2.push_back(unbounded ? 3.0e38f : (float)std::min(r2b * (moving ? 1.0 + 1e-6 : 1.0), 3.0e38));
         cull_w.push_back((float)w);
     }
+    // Box = six consecutive rectangles RectXY z1, RectXY z0, RectXZ y1, RectXZ y0, RectYZ x1, RectYZ x0 over one (x0 y0 z0) - (x1 y1 z1) and one instance
+    // chain (hitable.clj:500-511, spliced in by the flattener): the tree gets one leaf for the six (ext_box_test); z0 goes to slot 5 of the first record
+    std::vector<char> box_first((size_t)std::max(n_prims, 1), 0);
+    if (const char *e = std::getenv("RTMI_BOX_LEAF"); e && e[0] == '1') // (measured: make-final 22.1 ms with box leaves against 21.2 without -- six face tests per leaf cost more than the 1.8 node visits they save; kept for experiments)
+    for (int i = 0; i + 5 < n_world; ++i) {
+        static const int want[6] = {RTMI_PRIM_RECT_XY, RTMI_PRIM_RECT_XY, RTMI_PRIM_RECT_XZ, RTMI_PRIM_RECT_XZ, RTMI_PRIM_RECT_YZ, RTMI_PRIM_RECT_YZ};
+        bool ok = true;
+        for (int k = 0; k < 6 && ok; ++k) {
+            ok = pk[(size_t)i + k] == want[k];
+            if (prim_xform) ok = ok && prim_xform[2 * (i + k)] == prim_xform[2 * i] && prim_xform[2 * (i + k) + 1] == prim_xform[2 * i + 1];
+        }
+        if (!ok) continue;
+        const double *q = prim_geom + (size_t)i * RTMI_PRIM_STRIDE;
+        const double x0 = q[0], y0 = q[1], x1 = q[2], y1 = q[3], z1 = q[4], z0 = q[RTMI_PRIM_STRIDE + 4];
+        const double expect[6][5] = {{x0, y0, x1, y1, z1}, {x0, y0, x1, y1, z0}, {x0, z0, x1, z1, y1}, {x0, z0, x1, z1, y0}, {y0, z0, y1, z1, x1}, {y0, z0, y1, z1, x0}};
+        for (int k = 0; k < 6 && ok; ++k) for (int c = 0; c < 5; ++c) ok = ok && std::memcmp(&q[(size_t)k * RTMI_PRIM_STRIDE + c], &expect[k][c], sizeof(double)) == 0; // bit for bit
+        if (!ok) continue;
+        box_first[(size_t)i] = 1;
+        exact12[(size_t)i * 12 + 5] = z0;
+        i += 5;
+    }
     const size_t n_pad = n_prims > 0 ? ((size_t)n_prims + 7) / 8 * 8 + 8 : 0;
     if (n_prims > 0) {
         const std::vector<double> last12(exact12.begin() + (size_t)(n_prims - 1) * 12, exact12.begin() + (size_t)n_prims * 12);
@@ -1693,11 +1825,11 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     for (int k = 0; k < n_media; ++k) d.media_idx[k] = media[k];
     s->host_kind = pk;
     std::vector<int> grid_cells;
-    const std::vector<float> bvh_nodes = build_bvh(d, n_world, pk.data(), wbox, bounded, cam, !has_ext, grid_cells);
+    const std::vector<float> bvh_nodes = build_bvh(d, n_world, pk.data(), wbox, bounded, cam, !has_ext, grid_cells, box_first, &s->bvh_depth);
     s->bvh_node_count = (int)(bvh_nodes.size() / (d.bvh_node16 ? 8 : 16));
     if (std::getenv("RTMI_DEBUG"))
-        fprintf(stderr, "[rtmi] tree: %d node records of %d bytes (%.2f MB), %d big primitives; entry grid %d x %d cells, %zu rectangle trees\n", s->bvh_node_count,
-                d.bvh_node16 ? 32 : 64, s->bvh_node_count * (d.bvh_node16 ? 32.0 : 64.0) / 1e6, d.n_big, d.grid_n, d.grid_n, grid_cells.size());
+        fprintf(stderr, "[rtmi] tree: %d node records of %d bytes (%.2f MB), depth %d, %d big primitives, %d box leaves; entry grid %d x %d cells, %zu rectangle trees\n", s->bvh_node_count,
+                d.bvh_node16 ? 32 : 64, s->bvh_node_count * (d.bvh_node16 ? 32.0 : 64.0) / 1e6, s->bvh_depth, d.n_big, (int)std::count(box_first.begin(), box_first.end(), (char)1), d.grid_n, d.grid_n, grid_cells.size());
     if (!rc) rc = upload(s, bvh_nodes, &d.bvh_nodes);
     if (!rc) rc = upload(s, grid_cells, &d.grid_cells);
     std::vector<int> moving_all;

@@ -1411,6 +1411,69 @@ __device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P
     }
 }
 
+// ---- Box (hitable.clj:491-511) as ONE leaf --------------------------------------------------------------------------------------------
+// (box :p0 :p1) is a Hitlist of six rectangles -- RectXY k = z1, (flipped) RectXY k = z0, RectXZ k = y1, (flipped) RectXZ k = y0, RectYZ k = x1,
+// (flipped) RectYZ k = x0 -- that the flattener splices into the world as six consecutive primitives with one instance chain.  The host recognises
+// such a run (scene creation: kinds, chain and all thirty parameters must agree) and hands the tree ONE leaf for it (leaf-code bit RTMI_LEAF_BOX,
+// index = the first rectangle; z0 rides in the otherwise unused slot 5 of that rectangle's record): a ray that meets the box pays one exact-test
+// phase and no node visits among the faces, where six flat leaves cost it three to five visits and two to four phases.  The six tests below are
+// the six RectXY/XZ/YZ.hit? bodies (hitable.clj:269-363: t = (k - o_a) / d_a, t-min <= t, the point inside the rectangle, bounds inclusive), each
+// folded into the any-order state under ITS OWN primitive index -- exactly what six calls of ext_prim_test do --, evaluated on the chain's local ray
+// computed once instead of six times.
+//
+// The three divisors are the local direction's components, two faces each: RefinedRcp keeps the refined reciprocal of the IEEE division sequence
+// (Quot's argument, rtmi_device.h above; signed divisors: every step of the sequence is odd in a) and a face's t costs the sequence's last three
+// operations.  Same bits whenever the division would not have rescaled (2^-200 <= |d_a| <= 2^200, 2^-969 <= |k - o_a| < 2^568); outside the
+// numerator's range |t| < 2^-768 or >= 2^368 or NaN with either form, which fails t-min <= t or t <= closest-so-far alike for t-min >= 2^-300
+// and a closest hit <= 2^200 (checked per lane: `fast`).
+#define RTMI_LEAF_BOX 0x20000000
+struct RefinedRcp { double a, r; };
+__device__ inline RefinedRcp refined_rcp(double a) {
+    double r = __builtin_amdgcn_rcp(a);
+    r = ::fma(r, ::fma(-a, r, 1.0), r);
+    return RefinedRcp{a, ::fma(r, ::fma(-a, r, 1.0), r)};
+}
+__device__ inline bool rcp_in_range(double a) { return ((unsigned)__double2hiint(a) & 0x7fffffffu) - (823u << 20) < (400u << 20); } // biased exponent in [823, 1223)
+__device__ inline double div_by(double n, const RefinedRcp &d, bool fast) {
+    if (__builtin_expect(!fast, 0)) return n / d.a;
+    const double q = n * d.r;
+    return ::fma(::fma(-d.a, q, n), d.r, q);
+}
+// one face: the rectangle in the plane x_a = k, in-plane coordinates (u, v) within [u0, u1] x [v0, v1]
+__device__ inline void box_face(double k, double oa, const RefinedRcp &da, bool fast, double ou, double du, double ov, double dv, double u0, double u1, double v0, double v1,
+                                double tmin, int idx, ExtHit &H) {
+    const double t = div_by(k - oa, da, fast);
+    if (t >= tmin) {
+        const double x = ou + t * du, y = ov + t * dv;
+        if (x >= u0 && x <= u1 && y >= v0 && y <= v1) ext_update(H, t, idx, true);
+    }
+}
+// r: the ray in the box's frame (ext_local_ray of the six rectangles' common chain); rec: the first rectangle's record (x0 y0 x1 y1 z1 z0)
+__device__ inline void ext_box_faces(const LocalRay &r, double x0, double y0, double x1, double y1, double z1, double z0, double tmin, int idx, ExtHit &H) {
+    const bool fast = rcp_in_range(r.dx) && rcp_in_range(r.dy) && rcp_in_range(r.dz) && tmin >= 0x1p-300 && H.t <= 0x1p200;
+    const RefinedRcp qx = refined_rcp(r.dx), qy = refined_rcp(r.dy), qz = refined_rcp(r.dz);
+    box_face(z1, r.oz, qz, fast, r.ox, r.dx, r.oy, r.dy, x0, x1, y0, y1, tmin, idx, H);     // RectXY x0 y0 x1 y1 z1
+    box_face(z0, r.oz, qz, fast, r.ox, r.dx, r.oy, r.dy, x0, x1, y0, y1, tmin, idx + 1, H); // RectXY x0 y0 x1 y1 z0
+    box_face(y1, r.oy, qy, fast, r.ox, r.dx, r.oz, r.dz, x0, x1, z0, z1, tmin, idx + 2, H); // RectXZ x0 z0 x1 z1 y1
+    box_face(y0, r.oy, qy, fast, r.ox, r.dx, r.oz, r.dz, x0, x1, z0, z1, tmin, idx + 3, H); // RectXZ x0 z0 x1 z1 y0
+    box_face(x1, r.ox, qx, fast, r.oy, r.dy, r.oz, r.dz, y0, y1, z0, z1, tmin, idx + 4, H); // RectYZ y0 z0 y1 z1 x1
+    box_face(x0, r.ox, qx, fast, r.oy, r.dy, r.oz, r.dz, y0, y1, z0, z1, tmin, idx + 5, H); // RectYZ y0 z0 y1 z1 x0
+}
+template <bool UNIFORM = false>
+__device__ inline void ext_box_test(SceneRef sc, int idx, const Path<double> &P, double tmin, ExtHit &H) {
+    const int4 info = ext_ld_info<UNIFORM>(sc.ext_info, idx);
+    const LocalRay r = ext_local_ray<UNIFORM>(sc, info.z, info.w, P);
+    const size_t gi = (size_t)idx * 12;
+    if (UNIFORM) {
+        ext_box_faces(r, ext_ld<true>(sc.exact12, gi), ext_ld<true>(sc.exact12, gi + 1), ext_ld<true>(sc.exact12, gi + 2), ext_ld<true>(sc.exact12, gi + 3),
+                      ext_ld<true>(sc.exact12, gi + 4), ext_ld<true>(sc.exact12, gi + 5), tmin, idx, H);
+    } else {
+        const double2 *g = reinterpret_cast<const double2 *>(sc.exact12 + gi);
+        const double2 g0 = g[0], g1 = g[1], g2 = g[2];
+        ext_box_faces(r, g0.x, g0.y, g1.x, g1.y, g2.x, g2.y, tmin, idx, H);
+    }
+}
+
 // ConstantMedium.hit? (hitable.clj:518-541): closest boundary hit on the whole line, closest boundary hit after it, the
 // segment between them clipped to [t-min, t-max]; then ONE draw of the path's stream: hit-distance = -(log xi)/density
 // against the length of the segment decides whether (where) the ray scatters inside.  t-min/t-max are the caller's
@@ -1424,6 +1487,37 @@ __device__ inline void ext_medium_chord(SceneRef sc, int idx, const Path<double>
     const size_t gi = (size_t)idx * 12; // idx comes from media_idx: wave-uniform
     const int first = (int)ext_ld<true>(sc.exact12, gi + 1), count = (int)ext_ld<true>(sc.exact12, gi + 2);
     C.idx = idx; C.ok = false; C.t1 = C.t2 = C.mag = 0.0;
+    if (count == 1) { // (wave-uniform) a boundary that is ONE plain sphere -- make-final's two media, make-subsurface-sphere --: both closest-hit scans evaluate the same
+        // quadratic (hitable.clj:183-207), so it is evaluated once: the scan over the whole line takes the first root, the scan from first root + 0.0001 the second
+        // (the first cannot exceed itself + 0.0001).  The same operations on the same operands as the two generic scans below; anything unusual (a root that is
+        // not finite, a moving sphere) takes them.
+        const int4 binfo = ext_ld_info<true>(sc.ext_info, first);
+        if (binfo.x == RTMI_PRIM_SPHERE || binfo.x == RTMI_PRIM_UVSPHERE) {
+            const LocalRay r = ext_local_ray<true>(sc, binfo.z, binfo.w, P);
+            const size_t bi = (size_t)first * 12;
+            Prim4<double> s;
+            s.cx = ext_ld<true>(sc.exact12, bi); s.cy = ext_ld<true>(sc.exact12, bi + 1); s.cz = ext_ld<true>(sc.exact12, bi + 2); s.r2 = ext_ld<true>(sc.exact12, bi + 3);
+            Path<double> L; L.ox = r.ox; L.oy = r.oy; L.oz = r.oz; L.dx = r.dx; L.dy = r.dy; L.dz = r.dz;
+            const double a = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
+            double bq, cq, disc;
+            sphere_test(s, L, a, bq, cq, disc);
+            if (!(disc >= 0.0)) { if (cnt) cnt[1] += 1u; return; } // the line misses the boundary: no first hit
+            const double sq = rt_sqrt(disc);
+            const double tA = (-bq - sq) / a;
+            const double tmin2 = tA + 0.0001;
+            if (tA > -FMAX && tA < FMAX && !(tA > tmin2)) { // the first scan's hit, and not the second scan's (else, i.e. never for finite roots: the generic scans)
+                if (cnt) cnt[1] += 2u;
+                if (tmin2 >= 0.0 && bq > 0.0 && cq > 0.0) return; // ext_prim_test's exact early-out of the second scan: both roots <= 0
+                const double tB = (-bq + sq) / a;
+                if (!(tB > tmin2 && tB < FMAX)) return; // the second scan finds nothing
+                const int4 info = ext_ld_info<true>(sc.ext_info, idx);
+                const LocalRay rm = ext_local_ray<true>(sc, info.z, info.w, P);
+                C.mag = rt_sqrt(dot3(rm.dx, rm.dy, rm.dz, rm.dx, rm.dy, rm.dz));
+                C.t1 = tA; C.t2 = tB; C.ok = true;
+                return;
+            }
+        }
+    }
     ExtHit h1 = {FMAX, 0x7fffffff, -1, false};
     for (int k = 0; k < count; ++k) ext_prim_test<true>(sc, first + k, P, -FMAX, h1); // idx (a medium of media_idx) is wave-uniform
     if (cnt) cnt[1] += (unsigned)count; // exact tests of the boundary's primitives
@@ -1495,7 +1589,13 @@ __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> 
         cur = bvh_cursor_at_root(sc, stack);
         RTMI_PH(PH_BIG)
     }
-    auto leaf = [&](int code) { const int idx = (~code) & 0x3fffffff; if (idx >= lo && idx < hi) ext_prim_test<false>(sc, idx, P, tmin, H); };
+    auto leaf = [&](int code) { // one primitive, or the six faces of a Box (RTMI_LEAF_BOX: one chain, one local ray, three divisors)
+        const int bits = ~code, idx = bits & 0x1fffffff;
+        if (idx >= lo && idx < hi) {
+            if (bits & RTMI_LEAF_BOX) { if (COUNT) cnt[1] += 5; ext_box_test<false>(sc, idx, P, tmin, H); }
+            else ext_prim_test<false>(sc, idx, P, tmin, H);
+        }
+    };
     auto best = [&]() { return ext_best_hi(H); };
     bvh_traverse<COUNT, SLICE>(sc, r, cur, min_lanes, leaf, best, cnt);
     if (SLICE && cur.node != RTMI_BVH_EMPTY) { // suspended
