@@ -281,11 +281,16 @@ int rtmi_probe_rng(rtmi_ctx *ctx, int32_t precision, uint64_t key, uint64_t d0, 
 uint64_t rtmi_sample_key(uint64_t seed, uint64_t pixel, uint64_t sample);
 /* correctly-rounded device arithmetic check: out[k] = {a/b, sqrt(|a|), a*b+c unfused} */
 int rtmi_probe_arith(rtmi_ctx *ctx, int32_t n, const double *abc, double *out);
-/* the path's own FP64 helpers, one thread per triple (a, b, c):  out[9k..] = { sqrt(a) (fast path when the whole wave's arguments are
- * finite and >= 2^-767, libm otherwise), atan2(a, b), asin(a), u and v of get-sphere-uv for the unit normal (a, b, c) (hitable.clj:128-139),
- * a / b through the per-ray reciprocal of the sphere roots (t-min / t-max decide with b whether the wave takes it), a / (2 pi) by the
- * constant-divisor form, 1.0 if the lane took the reciprocal path else 0.0, the traversal's float bound of a closest hit at t = c: a float >= c
- * within two ulps (FLT_MAX beyond the float range) } */
+/* the path's own FP64 helpers, one thread per triple (a, b, c):  out[n_slots k + j], j < n_slots <= RTMI_PROBE_MATH_SLOTS =
+ * { 0 sqrt(a) (fast path for finite arguments >= 2^-767, libm otherwise), 1 atan2(a, b), 2 asin(a), 3, 4 u and v of get-sphere-uv for the unit normal
+ * (a, b, c) (hitable.clj:128-139), 5 a / b through the per-ray reciprocal of the sphere roots (t-min / t-max decide with b whether the lane takes
+ * it), 6 a / (2 pi) by the constant-divisor form, 7 1.0 if the lane took the reciprocal path else 0.0, 8 the traversal's float bound of a closest hit at
+ * t = c: a float >= c within two ulps (FLT_MAX beyond the float range), 9 log(a) as ConstantMedium's free-flight distance evaluates it for a draw a in
+ * [0, 1), 10 a / b through the refined reciprocal of a SIGNED divisor (a rectangle's t = (k - o) / d), 11 1.0 if slot 10 took the reciprocal path }.
+ * The caller's buffer holds n * n_slots doubles: the slot count is an argument so that a host built against an older header is never overrun.
+ * rtmi_probe_math is the entry as first published: the first EIGHT slots (library version 203 wrote nine; from 204 on it is eight again). */
+#define RTMI_PROBE_MATH_SLOTS 12
+int rtmi_probe_math2(rtmi_ctx *ctx, int32_t n, const double *abc, double tmin, double tmax, int32_t n_slots, double *out);
 int rtmi_probe_math(rtmi_ctx *ctx, int32_t n, const double *abc, double tmin, double tmax, double *out);
 
 #ifdef __cplusplus

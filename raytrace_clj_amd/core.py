@@ -223,12 +223,13 @@ def probe_arith(abc, ctx=None):
 
 
 def probe_math(abc, tmin=0.001, tmax=3.4028234663852886e38, ctx=None):
-    """[n, 9]: sqrt(a), atan2(a, b), asin(a), sphere u, v of (a, b, c), a / b by the per-ray reciprocal, a / (2 pi), reciprocal path taken,
-    the traversal's float upper bound of c"""
+    """[n, 12]: sqrt(a), atan2(a, b), asin(a), sphere u, v of (a, b, c), a / b by the per-ray reciprocal, a / (2 pi), reciprocal path taken,
+    the traversal's float upper bound of c, the medium's log(a), a / b by the refined reciprocal of a signed divisor, that path taken"""
     ctx = ctx or default_context()
     abc = np.ascontiguousarray(abc, np.float64).reshape(-1, 3)
-    out = np.zeros((len(abc), 9))
-    check(_ffi.lib().rtmi_probe_math(ctx.handle, len(abc), ptr(abc), tmin, tmax, ptr(out)))
+    slots = 12
+    out = np.zeros((len(abc), slots))
+    check(_ffi.lib().rtmi_probe_math2(ctx.handle, len(abc), ptr(abc), tmin, tmax, slots, ptr(out)))
     return out
 
 

@@ -148,6 +148,7 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
             const int m = k < sc.n_media ? sc.media_idx[k] : sc.n_all;
             if (m > prev) {
                 if (bvh) scan_bvh_ext<false, COUNT>(sc, stack, P, a, tmin, H, nullptr, false, 0, cnt, prev, m);
+                else if (sc.small_scan) scan_small_ext(sc, P, tmin, H, prev, m);
                 else scan_all_cull_ext(sc, P, a, tmin, H, prev, m);
             }
             if (k < sc.n_media) ext_medium_test(sc, m, P, tmin, H.any ? H.t : tmax, H, chord, COUNT ? cnt : nullptr);
@@ -163,7 +164,8 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
             *mid = !done;
             if (!done) return;
         } else scan_bvh_ext<false, COUNT>(sc, stack, P, a, tmin, H, nullptr, false, 0, cnt);
-    } else scan_all_cull_ext(sc, P, a, tmin, H);
+    } else if (sc.small_scan) scan_small_ext(sc, P, tmin, H); // (wave-uniform)
+    else scan_all_cull_ext(sc, P, a, tmin, H);
     // media: after the surfaces, in primitive-index order = the order the reference's descent calls their hit? (and draws)
     RTMI_PH(PH_BVH_POST)
     MediumChord chord; chord.idx = -1; chord.ok = false; chord.t1 = chord.t2 = chord.mag = 0.0;
@@ -1489,7 +1491,7 @@ int check_render_args(rtmi_scene *s, int nx, int ny, int ns, int depth, int prec
 // ---- library / context -------------------------------------------------------------------------------
 RTMI_EXPORT const char *rtmi_last_error(void) { return g_err.c_str(); }
 RTMI_EXPORT const char *rtmi_backend_name(void) { return "hip-gfx950"; }
-RTMI_EXPORT int rtmi_version(void) { return 203; } // 203: rtmi_probe_math writes 9 values per triple (float_above)
+RTMI_EXPORT int rtmi_version(void) { return 204; } // 204: rtmi_probe_math2 (explicit slot count; rtmi_probe_math writes 8 values per triple again)
 RTMI_EXPORT uint64_t rtmi_sample_key(uint64_t seed, uint64_t pixel, uint64_t sample) { return sample_key(seed, pixel, sample); }
 
 RTMI_EXPORT int rtmi_init(int device, uint32_t flags, rtmi_ctx **out_ctx) {
@@ -1837,6 +1839,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     d.n_moving_all = (int)moving_all.size();
     if (!rc) rc = upload(s, moving_all, &d.moving_all);
     d.has_ext = has_ext ? 1 : 0;
+    { const char *e = std::getenv("RTMI_SMALL_SCAN"); d.small_scan = (has_ext && n_world <= RTMI_SMALL_SCAN_MAX && !(e && e[0] == '0')) ? 1 : 0; }
     if (!rc) rc = upload(s, ext_info, &d.ext_info);
     if (!rc) rc = upload(s, ext_xf, &d.ext_xf);
     if (!rc) rc = upload(s, cull20, &d.cull20);
@@ -2647,11 +2650,11 @@ RTMI_EXPORT int rtmi_probe_rng(rtmi_ctx *c, int32_t precision, uint64_t key, uin
 
 // the path's own FP64 helpers (rtmi_device.h): square root with the wave-uniform fast path, the table-driven atan2 / asin and the uv
 // formula of get-sphere-uv, the per-ray reciprocal of the sphere roots, division by a constant
-__global__ void probe_math_kernel(int n, const double *abc, double tmin, double tmax, double *out) {
+__global__ void probe_math_kernel(int n, const double *abc, double tmin, double tmax, int n_slots, double *out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const double a = abc[3 * k], b = abc[3 * k + 1], c = abc[3 * k + 2];
-    double *o = out + (size_t)k * 9;
+    double o[RTMI_PROBE_MATH_SLOTS];
     o[0] = rt_sqrt(a);
     const TrigTable K = trig_table();
     o[1] = rt_atan2(a, b, K);
@@ -2662,6 +2665,11 @@ __global__ void probe_math_kernel(int n, const double *abc, double tmin, double 
     o[6] = div_const(a, K[29], K[27]);
     o[7] = (double)q.fast;
     o[8] = (double)float_above(c); // the traversal's float bound of the closest hit so far: a float >= c, within two ulps
+    o[9] = rt_log_unit(a);         // ConstantMedium's free-flight log of a draw in [0, 1)
+    const bool fast = rcp_in_range(b) && tmin >= 0x1p-300 && tmax <= 0x1p200; // a rectangle's t = a / b by the refined reciprocal of a signed divisor (ext_box_faces, scan_small_ext)
+    o[10] = div_by(a, refined_rcp(b), fast);
+    o[11] = (double)fast;
+    for (int j = 0; j < n_slots; ++j) out[(size_t)k * n_slots + j] = o[j];
 }
 
 RTMI_EXPORT int rtmi_probe_arith(rtmi_ctx *c, int32_t n, const double *abc, double *out) {
@@ -2679,17 +2687,23 @@ RTMI_EXPORT int rtmi_probe_arith(rtmi_ctx *c, int32_t n, const double *abc, doub
     return RTMI_OK;
 }
 
-RTMI_EXPORT int rtmi_probe_math(rtmi_ctx *c, int32_t n, const double *abc, double tmin, double tmax, double *out) {
+// n_slots values per triple (1 .. RTMI_PROBE_MATH_SLOTS): the caller states how many its buffer holds per triple
+RTMI_EXPORT int rtmi_probe_math2(rtmi_ctx *c, int32_t n, const double *abc, double tmin, double tmax, int32_t n_slots, double *out) {
     if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
     if (n <= 0 || !abc || !out) return fail(RTMI_E_ARG, "bad arguments");
+    if (n_slots < 1 || n_slots > RTMI_PROBE_MATH_SLOTS) return fail(RTMI_E_ARG, "n_slots must be 1..%d", RTMI_PROBE_MATH_SLOTS);
     HIP_TRY(hipSetDevice(c->device));
     Tmp tmp;
     double *d_in = (double *)tmp.up(abc, (size_t)n * 3 * sizeof(double));
-    double *d_out = (double *)tmp.alloc((size_t)n * 9 * sizeof(double));
+    double *d_out = (double *)tmp.alloc((size_t)n * (size_t)n_slots * sizeof(double));
     if (!d_in || !d_out) return fail(RTMI_E_NOMEM, "probe buffers");
     const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(probe_math_kernel, dim3(grid), dim3(kBlock), 0, c->stream, n, d_in, tmin, tmax, d_out);
+    hipLaunchKernelGGL(probe_math_kernel, dim3(grid), dim3(kBlock), 0, c->stream, n, d_in, tmin, tmax, (int)n_slots, d_out);
     PROBE_EPILOGUE()
-    HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d_out, (size_t)n * (size_t)n_slots * sizeof(double), hipMemcpyDeviceToHost));
     return RTMI_OK;
+}
+// the entry as first published: EIGHT values per triple (version 203 wrote nine into the same signature; hosts built against either header get eight again)
+RTMI_EXPORT int rtmi_probe_math(rtmi_ctx *c, int32_t n, const double *abc, double tmin, double tmax, double *out) {
+    return rtmi_probe_math2(c, n, abc, tmin, tmax, 8, out);
 }

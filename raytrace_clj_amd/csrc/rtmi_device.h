@@ -55,6 +55,7 @@ struct DevScene {
     const int *grid_cells;   // [4][grid_n][grid_n] root codes: family wi + 2 wj = the tree over the (1 + wi) x (1 + wj) cells whose low corner is (row = z cell, column = x cell)
     // section 8(f3): rectangles / triangles and FlipNormals / Translate / RotateY instances (hitable.clj:269-511, 548-581)
     int has_ext;             // any primitive kind > 2, any instance wrapper, any flip
+    int small_scan;          // the flat scan of this mixed-kind world is scan_small_ext (n_all <= RTMI_SMALL_SCAN_MAX; RTMI_SMALL_SCAN=0 at scene creation: the culled scan)
     const int *ext_info;     // [n_all][4]: kind, FlipNormals parity, first xform, xform count (outermost first)
     const double *ext_xf;    // [n_xforms][4]: 0 | offset.xyz  (Translate)   or   1 | sin, cos, 0  (RotateY)
     int media_seq;           // RTMI_MEDIA_HITLIST: the world is a Hitlist (hitable.clj:15-26), a medium's hit? sees the t-max narrowed by the items before it
@@ -229,6 +230,32 @@ __device__ inline double rt_asin(double x, TrigTable K) {
     const double big = K[13] - ::fma(2.0, ::fma(s, r, s), -K[14]);
     return ::copysign(small ? ::fma(ax, r, ax) : big, x);
 }
+// log of a uniform draw u in [0, 1) (ConstantMedium's free-flight distance, hitable.clj:529: (Math/log (rand))).  The generic device log is ~100 instructions
+// of double-double arithmetic for any argument; a draw is 0 or a normal number in [2^-53, 1), so the fdlibm e_log kernel applies without its special cases
+// (x = 2^k (1 + f), sqrt(1/2) < 1 + f < sqrt(2), s = f / (2 + f), log(1 + f) = f - (hfsq - s (hfsq + R(s^2)))): < 1 ulp, like a JVM's or a host libm's own log --
+// the one operation of a medium hit that is not bit-comparable across math libraries anyway.  log(0) = -inf (no hit: the distance is +inf).
+__device__ inline double rt_log_unit(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01, Lg7 = 1.479819860511658591e-01;
+    int hx = __double2hiint(x);
+    const unsigned lx = (unsigned)__double2loint(x);
+    if (!(x > 0.0) || hx >= 0x7ff00000) return x == 0.0 ? -__builtin_inf() : ::log(x); // 0, and what a draw never is (negative, inf, NaN)
+    if (hx < 0x00100000) return ::log(x);                                                // (denormal: never a draw)
+    int k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int i = (hx + 0x95f64) & 0x100000;
+    const double m = __hiloint2double(hx | (i ^ 0x3ff00000), (int)lx); // 1 + f in [sqrt(1/2), sqrt(2))
+    k += i >> 20;
+    const double f = m - 1.0, dk = (double)k;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * ::fma(w, ::fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * ::fma(w, ::fma(w, ::fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1, hfsq = 0.5 * f * f;
+    return ::fma(dk, ln2_hi, -((hfsq - ::fma(s, hfsq + R, dk * ln2_lo)) - f));
+}
+
 // x / c for a constant c with rc = RN(1 / c): q = RN(x rc) is within an ulp, r = x - c q is exact in one fma, and RN(q + r rc) is the
 // correctly rounded quotient (Markstein) -- the same value as the IEEE division the reference performs, in 3 instructions, not ~14
 __device__ inline double div_const(double x, double c, double rc) {
@@ -1355,62 +1382,6 @@ __device__ inline void rect_axes(int kind, int &ax, int &ua, int &va) {
     va = kind == RTMI_PRIM_RECT_XY ? 1 : 2;
 }
 
-// hit? of primitive idx (any kind, through its instance chain) folded into the any-order state
-template <bool UNIFORM = false>
-__device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P, double tmin, ExtHit &H) {
-    const int4 info = ext_ld_info<UNIFORM>(sc.ext_info, idx);
-    const int kind = info.x;
-    if (kind == RTMI_PRIM_MEDIUM) return; // media are evaluated after the surfaces, in index order (ext_medium_test)
-    const LocalRay r = ext_local_ray<UNIFORM>(sc, info.z, info.w, P);
-    const size_t gi = (size_t)idx * 12;
-    const double g0 = ext_ld<UNIFORM>(sc.exact12, gi), g1 = ext_ld<UNIFORM>(sc.exact12, gi + 1), g2 = ext_ld<UNIFORM>(sc.exact12, gi + 2),
-                 g3 = ext_ld<UNIFORM>(sc.exact12, gi + 3);
-    if (kind <= RTMI_PRIM_MOVING) {
-        Prim4<double> s;
-        s.cx = g0; s.cy = g1; s.cz = g2; s.r2 = g3;
-        if (kind == RTMI_PRIM_MOVING) {
-            const double g4 = ext_ld<UNIFORM>(sc.exact12, gi + 4), g5 = ext_ld<UNIFORM>(sc.exact12, gi + 5), g6 = ext_ld<UNIFORM>(sc.exact12, gi + 6);
-            const double t0 = ext_ld<UNIFORM>(sc.exact12, gi + 7), t1 = ext_ld<UNIFORM>(sc.exact12, gi + 8);
-            const double f = (P.time - t0) / (t1 - t0), omf = 1.0 - f;
-            s.cx = g0 * omf + g4 * f; s.cy = g1 * omf + g5 * f; s.cz = g2 * omf + g6 * f;
-        }
-        Path<double> L; L.ox = r.ox; L.oy = r.oy; L.oz = r.oz; L.dx = r.dx; L.dy = r.dy; L.dz = r.dz;
-        const double a = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
-        double bq, cq, disc;
-        sphere_test(s, L, a, bq, cq, disc);
-        if (disc >= 0.0 && !(tmin >= 0.0 && bq > 0.0 && cq > 0.0)) {
-            const double sq = rt_sqrt(disc);
-            double t = (-bq - sq) / a;
-            if (!(t > tmin)) t = (-bq + sq) / a;
-            if (t > tmin) ext_update(H, t, idx, false);
-        }
-    } else if (kind <= RTMI_PRIM_RECT_YZ) {
-        const double gk = ext_ld<UNIFORM>(sc.exact12, gi + 4);
-        // the rectangle's plane axis a and its two in-plane axes u, v
-        auto rect = [&](double oa, double da, double ou, double du, double ov, double dv) {
-            const double t = (gk - oa) / da;
-            if (t >= tmin) {
-                const double x = ou + t * du, y = ov + t * dv;
-                if (x >= g0 && x <= g2 && y >= g1 && y <= g3) ext_update(H, t, idx, true);
-            }
-        };
-        if (UNIFORM) { // scalar branches on the kind, one copy of the test per kind: no selects, no indexed temporaries
-            if (kind == RTMI_PRIM_RECT_XY) rect(r.oz, r.dz, r.ox, r.dx, r.oy, r.dy);
-            else if (kind == RTMI_PRIM_RECT_XZ) rect(r.oy, r.dy, r.ox, r.dx, r.oz, r.dz);
-            else rect(r.ox, r.dx, r.oy, r.dy, r.oz, r.dz);
-        } else {
-            int ax, ua, va;
-            rect_axes(kind, ax, ua, va);
-            rect(pick3(ax, r.ox, r.oy, r.oz), pick3(ax, r.dx, r.dy, r.dz), pick3(ua, r.ox, r.oy, r.oz), pick3(ua, r.dx, r.dy, r.dz),
-                 pick3(va, r.ox, r.oy, r.oz), pick3(va, r.dx, r.dy, r.dz));
-        }
-    } else {
-        double u, v, t;
-        if (tri_mt(g0, g1, g2, g3, ext_ld<UNIFORM>(sc.exact12, gi + 4), ext_ld<UNIFORM>(sc.exact12, gi + 5), ext_ld<UNIFORM>(sc.exact12, gi + 6),
-                   ext_ld<UNIFORM>(sc.exact12, gi + 7), ext_ld<UNIFORM>(sc.exact12, gi + 8), r, u, v, t) && t >= tmin) ext_update(H, t, idx, true);
-    }
-}
-
 // ---- Box (hitable.clj:491-511) as ONE leaf --------------------------------------------------------------------------------------------
 // (box :p0 :p1) is a Hitlist of six rectangles -- RectXY k = z1, (flipped) RectXY k = z0, RectXZ k = y1, (flipped) RectXZ k = y0, RectYZ k = x1,
 // (flipped) RectYZ k = x0 -- that the flattener splices into the world as six consecutive primitives with one instance chain.  The host recognises
@@ -1471,6 +1442,99 @@ __device__ inline void ext_box_test(SceneRef sc, int idx, const Path<double> &P,
         const double2 *g = reinterpret_cast<const double2 *>(sc.exact12 + gi);
         const double2 g0 = g[0], g1 = g[1], g2 = g[2];
         ext_box_faces(r, g0.x, g0.y, g1.x, g1.y, g2.x, g2.y, tmin, idx, H);
+    }
+}
+
+// hit? of primitive idx (any kind) on the ray r already taken through its instance chain, folded into the any-order state.
+// q (optional): the refined reciprocals of r's direction components (ext_box_faces) -- a rectangle's t = (k - o_a) / d_a then costs the division's last
+// three operations (`fast`, per lane: see RefinedRcp); nullptr: the plain division.
+template <bool UNIFORM = false>
+__device__ inline void ext_prim_test_local(SceneRef sc, int idx, int kind, const LocalRay &r, double time, double tmin, ExtHit &H, const RefinedRcp *q = nullptr, bool fast = false) {
+    const size_t gi = (size_t)idx * 12;
+    const double g0 = ext_ld<UNIFORM>(sc.exact12, gi), g1 = ext_ld<UNIFORM>(sc.exact12, gi + 1), g2 = ext_ld<UNIFORM>(sc.exact12, gi + 2),
+                 g3 = ext_ld<UNIFORM>(sc.exact12, gi + 3);
+    if (kind <= RTMI_PRIM_MOVING) {
+        Prim4<double> s;
+        s.cx = g0; s.cy = g1; s.cz = g2; s.r2 = g3;
+        if (kind == RTMI_PRIM_MOVING) {
+            const double g4 = ext_ld<UNIFORM>(sc.exact12, gi + 4), g5 = ext_ld<UNIFORM>(sc.exact12, gi + 5), g6 = ext_ld<UNIFORM>(sc.exact12, gi + 6);
+            const double t0 = ext_ld<UNIFORM>(sc.exact12, gi + 7), t1 = ext_ld<UNIFORM>(sc.exact12, gi + 8);
+            const double f = (time - t0) / (t1 - t0), omf = 1.0 - f;
+            s.cx = g0 * omf + g4 * f; s.cy = g1 * omf + g5 * f; s.cz = g2 * omf + g6 * f;
+        }
+        Path<double> L; L.ox = r.ox; L.oy = r.oy; L.oz = r.oz; L.dx = r.dx; L.dy = r.dy; L.dz = r.dz;
+        const double a = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
+        double bq, cq, disc;
+        sphere_test(s, L, a, bq, cq, disc);
+        if (disc >= 0.0 && !(tmin >= 0.0 && bq > 0.0 && cq > 0.0)) {
+            const double sq = rt_sqrt(disc);
+            double t = (-bq - sq) / a;
+            if (!(t > tmin)) t = (-bq + sq) / a;
+            if (t > tmin) ext_update(H, t, idx, false);
+        }
+    } else if (kind <= RTMI_PRIM_RECT_YZ) {
+        const double gk = ext_ld<UNIFORM>(sc.exact12, gi + 4);
+        // the rectangle's plane axis a and its two in-plane axes u, v
+        auto rect = [&](double oa, double da, double ou, double du, double ov, double dv) {
+            const double t = (gk - oa) / da;
+            if (t >= tmin) {
+                const double x = ou + t * du, y = ov + t * dv;
+                if (x >= g0 && x <= g2 && y >= g1 && y <= g3) ext_update(H, t, idx, true);
+            }
+        };
+        if (UNIFORM) { // scalar branches on the kind, one copy of the test per kind: no selects, no indexed temporaries
+            if (q) { // g = (u0 v0 u1 v1)
+                if (kind == RTMI_PRIM_RECT_XY) box_face(gk, r.oz, q[2], fast, r.ox, r.dx, r.oy, r.dy, g0, g2, g1, g3, tmin, idx, H);
+                else if (kind == RTMI_PRIM_RECT_XZ) box_face(gk, r.oy, q[1], fast, r.ox, r.dx, r.oz, r.dz, g0, g2, g1, g3, tmin, idx, H);
+                else box_face(gk, r.ox, q[0], fast, r.oy, r.dy, r.oz, r.dz, g0, g2, g1, g3, tmin, idx, H);
+            }
+            else if (kind == RTMI_PRIM_RECT_XY) rect(r.oz, r.dz, r.ox, r.dx, r.oy, r.dy);
+            else if (kind == RTMI_PRIM_RECT_XZ) rect(r.oy, r.dy, r.ox, r.dx, r.oz, r.dz);
+            else rect(r.ox, r.dx, r.oy, r.dy, r.oz, r.dz);
+        } else {
+            int ax, ua, va;
+            rect_axes(kind, ax, ua, va);
+            rect(pick3(ax, r.ox, r.oy, r.oz), pick3(ax, r.dx, r.dy, r.dz), pick3(ua, r.ox, r.oy, r.oz), pick3(ua, r.dx, r.dy, r.dz),
+                 pick3(va, r.ox, r.oy, r.oz), pick3(va, r.dx, r.dy, r.dz));
+        }
+    } else {
+        double u, v, t;
+        if (tri_mt(g0, g1, g2, g3, ext_ld<UNIFORM>(sc.exact12, gi + 4), ext_ld<UNIFORM>(sc.exact12, gi + 5), ext_ld<UNIFORM>(sc.exact12, gi + 6),
+                   ext_ld<UNIFORM>(sc.exact12, gi + 7), ext_ld<UNIFORM>(sc.exact12, gi + 8), r, u, v, t) && t >= tmin) ext_update(H, t, idx, true);
+    }
+}
+// hit? of primitive idx (any kind, through its instance chain) folded into the any-order state
+template <bool UNIFORM = false>
+__device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P, double tmin, ExtHit &H) {
+    const int4 info = ext_ld_info<UNIFORM>(sc.ext_info, idx);
+    if (info.x == RTMI_PRIM_MEDIUM) return; // media are evaluated after the surfaces, in index order (ext_medium_test)
+    ext_prim_test_local<UNIFORM>(sc, idx, info.x, ext_local_ray<UNIFORM>(sc, info.z, info.w, P), P.time, tmin, H);
+}
+
+// The scan of a SMALL mixed-kind world (a Cornell box's 18 rectangles; what option flat_below sends here): all primitives in Hitlist order, every index
+// wave-uniform -- scalar loads, scalar branches on kind and chain.  Consecutive primitives that share an instance chain (a Box's six rectangles under its
+// Translate / RotateY wrappers, hitable.clj:391-486; the chain-less walls) share the LOCAL RAY -- evaluated once per run of equal chains instead of once per
+// rectangle -- and the refined reciprocals of its three direction components: a rectangle's t costs three operations instead of the division's eleven.  No cull:
+// a rectangle test at that price (~15 instructions) costs what the FP32 cull of its bounding sphere does.  Bit-identical to scan_all_cull_ext (RefinedRcp).
+#ifndef RTMI_SMALL_SCAN_MAX
+#define RTMI_SMALL_SCAN_MAX 64
+#endif
+__device__ inline void scan_small_ext(SceneRef sc, const Path<double> &P, double tmin, ExtHit &H, int lo = 0, int hi = 0x7fffffff) {
+    const int n = min(sc.n_all, hi);
+    int cf = -1, cc = -1; // the chain the cached local ray belongs to
+    LocalRay lr = {P.ox, P.oy, P.oz, P.dx, P.dy, P.dz};
+    RefinedRcp q[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+    bool fast = false;
+    for (int i = max(lo, 0); i < n; ++i) {
+        const int4 info = ext_ld_info<true>(sc.ext_info, i);
+        if (info.x == RTMI_PRIM_MEDIUM) continue;
+        if (info.z != cf || info.w != cc) { // (wave-uniform)
+            cf = info.z; cc = info.w;
+            lr = ext_local_ray<true>(sc, cf, cc, P);
+            q[0] = refined_rcp(lr.dx); q[1] = refined_rcp(lr.dy); q[2] = refined_rcp(lr.dz);
+            fast = rcp_in_range(lr.dx) && rcp_in_range(lr.dy) && rcp_in_range(lr.dz) && tmin >= 0x1p-300 && H.t <= 0x1p200;
+        }
+        ext_prim_test_local<true>(sc, i, info.x, lr, P.time, tmin, H, q, fast);
     }
 }
 
@@ -1541,7 +1605,7 @@ __device__ inline void ext_medium_test(SceneRef sc, int idx, Path<double> &P, do
     if (t1 < 0.0) t1 = 0.0;
     const double density = ext_ld<true>(sc.exact12, (size_t)idx * 12);
     const double dist_in = (t2 - t1) * C.mag;
-    const double hit_distance = -(::log(next_uniform(P)) / density);
+    const double hit_distance = -(rt_log_unit(next_uniform(P)) / density);
     if (hit_distance < dist_in) ext_update(H, t1 + hit_distance / C.mag, idx, true);
 }
 

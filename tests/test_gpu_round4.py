@@ -1,0 +1,154 @@
+"""GPU tests added in round 4: the helpers the mixed-kind kernels gained (the refined reciprocal of a signed divisor behind a rectangle's t, the
+medium's own log of a draw, the explicit slot count of the math probe), the scan of small mixed-kind worlds against the culled scan and the tree,
+Box runs as one leaf, and the bench line's new keys.  Everything goes through the C-ABI."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import raytrace_clj_amd as r
+from raytrace_clj_amd import core
+from raytrace_clj_amd import flatten as fl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_signed_refined_reciprocal_division():
+    """div_by (a rectangle's t = (k - o_a) / d_a with the local direction's refined reciprocal, hitable.clj:269-363): the IEEE quotient bit for bit for
+    divisors of EITHER sign wherever the division would not scale its operands; out-of-range divisors take the plain division per lane; numerators
+    the division would scale give a value that passes / fails t-min <= t <= closest like the quotient."""
+    rng = np.random.default_rng(11)
+    n = 64 * 400
+    a = (np.abs(rng.normal(0, 1, n)) * 10.0 ** rng.integers(-6, 7, n) + 1e-12) * rng.choice([-1.0, 1.0], n)
+    num = rng.normal(0, 1, n) * 10.0 ** rng.integers(-12, 13, n)
+    o = core.probe_math(np.stack([num, a, np.zeros(n)], axis=1))
+    assert np.all(o[:, 11] == 1.0) and np.array_equal(o[:, 10], num / a)
+    q = rng.uniform(1.0, 2.0, n)  # hard-to-round quotients around exact products
+    hard = (q * a) * (1.0 + rng.integers(-3, 4, n) * 2.0 ** -53)
+    o = core.probe_math(np.stack([hard, a, np.zeros(n)], axis=1))
+    assert np.all(o[:, 11] == 1.0) and np.array_equal(o[:, 10], hard / a)
+    a2 = a.copy()  # per lane: out-of-range divisors (an axis-parallel ray's zero component among them) take the plain division
+    a2[::64] = np.resize([1e-80, -1e80, 0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324], len(a2[::64]))
+    o = core.probe_math(np.stack([num, a2, np.zeros(n)], axis=1))
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        ref = num / a2
+    slow = np.zeros(n, bool)
+    slow[::64] = True
+    assert np.all(o[slow, 11] == 0.0) and np.all(o[~slow, 11] == 1.0) and np.array_equal(o[:, 10], ref, equal_nan=True)
+    for tmin, tmax in ((0.0, 3.4e38), (-3.4028234663852886e38, 3.4028234663852886e38), (0.001, np.inf)):  # a medium's boundary scans run from -FMAX: plain division
+        o = core.probe_math(np.stack([num, a, np.zeros(n)], axis=1), tmin=tmin, tmax=tmax)
+        assert np.all(o[:, 11] == 0.0) and np.array_equal(o[:, 10], num / a)
+    ext = np.resize(np.array([0.0, -0.0, 5e-324, -1e-310, 1e-300, -1e-295, 1e250, -1e290, 1.7e308, np.inf, -np.inf, np.nan]), n)
+    tmin, tmax = 0.001, 3.4028234663852886e38
+    o = core.probe_math(np.stack([ext, a, np.zeros(n)], axis=1), tmin=tmin, tmax=tmax)
+    with np.errstate(invalid="ignore", over="ignore", under="ignore"):
+        ref = ext / a
+    keep = (ref >= tmin) & (ref <= tmax)  # a rectangle's inclusive interval
+    assert np.array_equal((o[:, 10] >= tmin) & (o[:, 10] <= tmax), keep) and np.array_equal(o[keep, 10], ref[keep])
+
+
+def test_medium_log_of_a_draw():
+    """rt_log_unit: log of a draw in [0, 1) (hitable.clj:529) within one ulp of the host libm's on every kind of draw the stream produces -- k 2^-53 for
+    53-bit k, values next to 1, the smallest draws, powers of two and their neighbours -- and -inf at 0 (no hit)."""
+    rng = np.random.default_rng(5)
+    k = np.concatenate([rng.integers(1, 2 ** 53, 400000), 2 ** 53 - rng.integers(1, 4096, 50000), rng.integers(1, 4096, 50000),
+                        2 ** rng.integers(0, 53, 2000), 2 ** rng.integers(1, 53, 2000) - 1, 2 ** rng.integers(1, 52, 2000) + 1]).astype(np.float64)
+    u = k * 2.0 ** -53
+    o = core.probe_math(np.stack([u, np.ones_like(u), np.zeros_like(u)], axis=1))[:, 9]
+    ref = np.log(u)
+    err = np.abs(o - ref) / np.spacing(np.abs(ref))
+    assert err.max() <= 1.0, err.max()
+    o = core.probe_math(np.array([[0.0, 1.0, 0.0], [1.0, 1.0, 0.0], [0.5, 1.0, 0.0]]))[:, 9]
+    assert o[0] == -np.inf and o[1] == 0.0 and o[2] == np.log(0.5)
+
+
+def test_math_probe_slot_count_is_the_callers():
+    """rtmi_probe_math2 writes exactly n_slots values per triple; rtmi_probe_math (the entry as first published) writes EIGHT -- a host built against
+    the first header is not overrun (library version 203 wrote nine into that signature)."""
+    L = r._ffi.lib()
+    assert L.rtmi_version() >= 204
+    ctx = core.default_context()
+    abc = np.ascontiguousarray(np.array([[0.25, 2.0, 1.5], [0.5, -3.0, 2.5]]))
+    out = np.full(2 * 8 + 4, -777.0)
+    core.check(L.rtmi_probe_math(ctx.handle, 2, core.ptr(abc), 0.001, 3.4e38, core.ptr(out)))
+    assert np.all(out[16:] == -777.0) and out[0] == 0.5 and out[8] == np.sqrt(0.5)
+    for slots in (1, 9, 12):
+        out = np.full(2 * slots + 3, -777.0)
+        core.check(L.rtmi_probe_math2(ctx.handle, 2, core.ptr(abc), 0.001, 3.4e38, slots, core.ptr(out)))
+        assert np.all(out[2 * slots:] == -777.0) and out[0] == 0.5 and out[slots] == np.sqrt(0.5)
+    assert L.rtmi_probe_math2(ctx.handle, 2, core.ptr(abc), 0.001, 3.4e38, 13, core.ptr(out)) != 0
+    assert L.rtmi_probe_math2(ctx.handle, 2, core.ptr(abc), 0.001, 3.4e38, 0, core.ptr(out)) != 0
+
+
+def _device_scene(flat, accel):
+    ctx = core.default_context()
+    ctx.set_option("accel", accel)
+    return core.DeviceScene(flat), ctx
+
+
+def _probe_rays(flat, n, seed, accel):
+    """closest hits of n rays shot through the scene's bounding region, by the flat scan (0) or the tree (1)"""
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-50, 600, (n, 3))
+    d = rng.normal(0, 1, (n, 3))
+    rays = np.concatenate([o, d, rng.uniform(0, 1, (n, 1))], axis=1)
+    ds, ctx = _device_scene(flat, accel)
+    try:
+        return ds.probe_hit(rays, 0.001, 3.4028234663852886e38)
+    finally:
+        ds.close()
+        ctx.set_option("accel", 1)
+
+
+def _frame(flat, accel, nx, ns):
+    ds, ctx = _device_scene(flat, accel)
+    try:
+        return ds.render(nx, nx, ns)
+    finally:
+        ds.close()
+        ctx.set_option("accel", 1)
+
+
+def _cornell_smoke(nx, ny):
+    return r.scene.make_cornell_box(nx, ny, classic=False)
+
+
+@pytest.mark.parametrize("make", [r.scene.make_cornell_box, _cornell_smoke, r.scene.make_two_triangles, r.scene.make_example_light, r.scene.make_subsurface_sphere])
+def test_small_world_scan_is_bit_identical_to_the_culled_scan_and_the_tree(make, monkeypatch):
+    """scan_small_ext (the scan of a world of at most RTMI_SMALL_SCAN_MAX primitives: shared local rays, refined reciprocals, no cull) against the culled
+    scan (RTMI_SMALL_SCAN=0 at scene creation) and the tree: hit records of 60 000 rays bit for bit, and whole frames with their counters."""
+    flat = fl.flatten(make(96, 96))
+    monkeypatch.setenv("RTMI_FLAT_BELOW", "0")
+    ref = _probe_rays(flat, 60000, 3, 1)          # the tree
+    monkeypatch.setenv("RTMI_SMALL_SCAN", "0")
+    culled = _probe_rays(flat, 60000, 3, 0)       # the culled scan
+    f_culled = _frame(flat, 0, 96, 16)
+    monkeypatch.delenv("RTMI_SMALL_SCAN")
+    small = _probe_rays(flat, 60000, 3, 0)        # the small-world scan
+    assert np.array_equal(culled, ref, equal_nan=True) and np.array_equal(small, ref, equal_nan=True)
+    assert (ref[:, 0] > 0).sum() > 1000
+    f_tree, f_small = _frame(flat, 1, 96, 16), _frame(flat, 0, 96, 16)
+    for lin, q, cnt in (f_culled, f_small):
+        assert np.array_equal(lin, f_tree[0]) and np.array_equal(cnt, f_tree[2])
+
+
+def test_box_runs_as_one_leaf_are_bit_identical(monkeypatch):
+    """RTMI_BOX_LEAF=1: six consecutive rectangles that form a Box (hitable.clj:500-511) become one leaf of the tree (ext_box_test: one local ray, three
+    refined reciprocals, six faces under their own indices).  Same hits, same frames, same counters as six leaves -- make-final's 400 ground boxes and
+    the Cornell box's two rotated ones."""
+    for make, nx, ns in ((r.scene.make_final, 64, 8), (r.scene.make_cornell_box, 64, 8)):
+        flat = fl.flatten(make(nx, nx))
+        monkeypatch.setenv("RTMI_FLAT_BELOW", "0")
+        out = []
+        for box in ("0", "1"):
+            monkeypatch.setenv("RTMI_BOX_LEAF", box)
+            hits = _probe_rays(flat, 40000, 9, 1)
+            lin, q, cnt = _frame(flat, 1, nx, ns)
+            out.append((hits, lin, cnt))
+        assert np.array_equal(out[0][0], out[1][0], equal_nan=True) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
