@@ -1840,6 +1840,29 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     if (!rc) rc = upload(s, moving_all, &d.moving_all);
     d.has_ext = has_ext ? 1 : 0;
     { const char *e = std::getenv("RTMI_SMALL_SCAN"); d.small_scan = (has_ext && n_world <= RTMI_SMALL_SCAN_MAX && !(e && e[0] == '0')) ? 1 : 0; }
+    { // LeafRec (rtmi_device.h: ext_leaf_test): one 112-byte record per world primitive
+        std::vector<double> leaf_rec((size_t)std::max(n_prims, 1) * RTMI_LEAF_REC_DOUBLES, 0.0);
+        for (int i = 0; i < n_prims; ++i) {
+            double *q = &leaf_rec[(size_t)i * RTMI_LEAF_REC_DOUBLES];
+            const int kind = pk[(size_t)i];
+            const int xf_first = prim_xform ? prim_xform[2 * i] : 0, xf_count = prim_xform ? prim_xform[2 * i + 1] : 0;
+            int hdr[4] = {kind, 0, 0, 0};
+            const bool simple = (kind == RTMI_PRIM_SPHERE || kind == RTMI_PRIM_UVSPHERE || (kind >= RTMI_PRIM_RECT_XY && kind <= RTMI_PRIM_RECT_YZ)) && xf_count <= 2;
+            if (!simple) hdr[1] = 1; // generic: ext_prim_test
+            else {
+                for (int c = 0; c < 5; ++c) q[2 + c] = exact12[(size_t)i * 12 + c]; // sphere: c r*r (slot 4 unused) | rectangle: u0 v0 u1 v1 k
+                for (int k = 0; k < xf_count; ++k) {
+                    const double *xp = xform_param + (size_t)(xf_first + k) * 3;
+                    hdr[2 + k] = xform_kind[xf_first + k] == RTMI_XFORM_TRANSLATE ? 1 : 2;
+                    q[7 + 3 * k] = xp[0]; q[8 + 3 * k] = xp[1]; q[9 + 3 * k] = xp[2];
+                }
+                if (box_first[(size_t)i]) q[13] = exact12[(size_t)i * 12 + 5]; // z0 of the Box whose first face this rectangle is
+            }
+            std::memcpy(q, hdr, sizeof hdr);
+        }
+        if (!rc) rc = upload(s, leaf_rec, &d.leaf_rec);
+    }
+    ext_info.insert(ext_info.end(), {RTMI_PRIM_MEDIUM, 0, 0, 0}); // one record past the end: scan_small_ext requests primitive i + 1's records while it tests primitive i
     if (!rc) rc = upload(s, ext_info, &d.ext_info);
     if (!rc) rc = upload(s, ext_xf, &d.ext_xf);
     if (!rc) rc = upload(s, cull20, &d.cull20);

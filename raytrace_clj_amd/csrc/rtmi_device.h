@@ -56,6 +56,7 @@ struct DevScene {
     // section 8(f3): rectangles / triangles and FlipNormals / Translate / RotateY instances (hitable.clj:269-511, 548-581)
     int has_ext;             // any primitive kind > 2, any instance wrapper, any flip
     int small_scan;          // the flat scan of this mixed-kind world is scan_small_ext (n_all <= RTMI_SMALL_SCAN_MAX; RTMI_SMALL_SCAN=0 at scene creation: the culled scan)
+    const double *leaf_rec;  // [n_all][14]: everything a tree leaf's exact test reads, in ONE 112-byte record (LeafRec: one round trip instead of info -> chain -> geometry)
     const int *ext_info;     // [n_all][4]: kind, FlipNormals parity, first xform, xform count (outermost first)
     const double *ext_xf;    // [n_xforms][4]: 0 | offset.xyz  (Translate)   or   1 | sin, cos, 0  (RotateY)
     int media_seq;           // RTMI_MEDIA_HITLIST: the world is a Hitlist (hitable.clj:15-26), a medium's hit? sees the t-max narrowed by the items before it
@@ -1519,14 +1520,38 @@ __device__ inline void ext_prim_test(SceneRef sc, int idx, const Path<double> &P
 #ifndef RTMI_SMALL_SCAN_MAX
 #define RTMI_SMALL_SCAN_MAX 64
 #endif
+// The records of primitive i + 1 (info, first five geometry slots: a rectangle's whole record) are requested BEFORE primitive i is tested: the scalar loads'
+// latency runs under the test's vector instructions instead of in front of them (RTMI_SMALL_SCAN_PREFETCH).
+#ifndef RTMI_SMALL_SCAN_PREFETCH
+#define RTMI_SMALL_SCAN_PREFETCH 0 // measured: Cornell box 37.3 ms with the prefetch against 34.3 without -- four waves per SIMD already cover the scalar loads, and the extra SGPRs cost more
+#endif
+struct SmallRec { int4 info; double g0, g1, g2, g3, g4; };
+__device__ inline SmallRec small_rec(SceneRef sc, int i) {
+    SmallRec r;
+    r.info = ext_ld_info<true>(sc.ext_info, i);
+    const size_t gi = (size_t)i * 12;
+    r.g0 = ext_ld<true>(sc.exact12, gi); r.g1 = ext_ld<true>(sc.exact12, gi + 1); r.g2 = ext_ld<true>(sc.exact12, gi + 2); r.g3 = ext_ld<true>(sc.exact12, gi + 3);
+    r.g4 = ext_ld<true>(sc.exact12, gi + 4);
+    return r;
+}
 __device__ inline void scan_small_ext(SceneRef sc, const Path<double> &P, double tmin, ExtHit &H, int lo = 0, int hi = 0x7fffffff) {
     const int n = min(sc.n_all, hi);
     int cf = -1, cc = -1; // the chain the cached local ray belongs to
     LocalRay lr = {P.ox, P.oy, P.oz, P.dx, P.dy, P.dz};
     RefinedRcp q[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
     bool fast = false;
-    for (int i = max(lo, 0); i < n; ++i) {
+    int i = max(lo, 0);
+    if (i >= n) return;
+#if RTMI_SMALL_SCAN_PREFETCH
+    SmallRec nxt = small_rec(sc, i); // (the arrays are padded: index n is readable)
+    for (; i < n; ++i) {
+        const SmallRec rec = nxt;
+        nxt = small_rec(sc, i + 1);
+        const int4 info = rec.info;
+#else
+    for (; i < n; ++i) {
         const int4 info = ext_ld_info<true>(sc.ext_info, i);
+#endif
         if (info.x == RTMI_PRIM_MEDIUM) continue;
         if (info.z != cf || info.w != cc) { // (wave-uniform)
             cf = info.z; cc = info.w;
@@ -1534,6 +1559,14 @@ __device__ inline void scan_small_ext(SceneRef sc, const Path<double> &P, double
             q[0] = refined_rcp(lr.dx); q[1] = refined_rcp(lr.dy); q[2] = refined_rcp(lr.dz);
             fast = rcp_in_range(lr.dx) && rcp_in_range(lr.dy) && rcp_in_range(lr.dz) && tmin >= 0x1p-300 && H.t <= 0x1p200;
         }
+#if RTMI_SMALL_SCAN_PREFETCH
+        if (info.x >= RTMI_PRIM_RECT_XY && info.x <= RTMI_PRIM_RECT_YZ) { // a rectangle: its record is already here
+            if (info.x == RTMI_PRIM_RECT_XY) box_face(rec.g4, lr.oz, q[2], fast, lr.ox, lr.dx, lr.oy, lr.dy, rec.g0, rec.g2, rec.g1, rec.g3, tmin, i, H);
+            else if (info.x == RTMI_PRIM_RECT_XZ) box_face(rec.g4, lr.oy, q[1], fast, lr.ox, lr.dx, lr.oz, lr.dz, rec.g0, rec.g2, rec.g1, rec.g3, tmin, i, H);
+            else box_face(rec.g4, lr.ox, q[0], fast, lr.oy, lr.dy, lr.oz, lr.dz, rec.g0, rec.g2, rec.g1, rec.g3, tmin, i, H);
+            continue;
+        }
+#endif
         ext_prim_test_local<true>(sc, i, info.x, lr, P.time, tmin, H, q, fast);
     }
 }
@@ -1609,6 +1642,63 @@ __device__ inline void ext_medium_test(SceneRef sc, int idx, Path<double> &P, do
     if (hit_distance < dist_in) ext_update(H, t1 + hit_distance / C.mag, idx, true);
 }
 
+// ---- a tree leaf's exact test from ONE record ------------------------------------------------------------------------------------------------
+// ext_prim_test reads a primitive the way the flattened scene stores it: its info (kind, chain slice), then the chain's transforms, then the geometry --
+// three dependent trips to the vector cache per leaf, at the 18 lanes a mixed-kind leaf phase runs with, and four waves per SIMD do not cover them
+// (make-final: 24 % of the waves' time).  The host packs what the common leaves need into one 112-byte record per primitive (seven 16-byte loads issued
+// together): header {kind, generic?, transform 1, transform 2} (transform: 0 none, 1 Translate, 2 RotateY; outermost first), five geometry values (a sphere's
+// c r^2, a rectangle's u0 v0 u1 v1 k), two transforms' parameters (offset.xyz | sin cos -), and z0 of a Box leaf.  Primitives that need more (MovingSphere,
+// Triangle, chains longer than two wrappers) are flagged generic and take ext_prim_test.  The arithmetic is ext_local_ray's and ext_prim_test_local's.
+#define RTMI_LEAF_REC_DOUBLES 14
+#ifndef RTMI_LEAF_RECORDS
+#define RTMI_LEAF_RECORDS 1
+#endif
+__device__ inline void leaf_xform(int xk, double a, double b, double c, LocalRay &r) {
+    if (xk == 1) { r.ox = r.ox - a; r.oy = r.oy - b; r.oz = r.oz - c; } // Translate: origin - offset (hitable.clj:394)
+    else if (xk == 2) {                                                  // RotateY: a = sin, b = cos (hitable.clj:423-429)
+        const double ox = b * r.ox - a * r.oz, oz = a * r.ox + b * r.oz;
+        const double dx = b * r.dx - a * r.dz, dz = a * r.dx + b * r.dz;
+        r.ox = ox; r.oz = oz; r.dx = dx; r.dz = dz;
+    }
+}
+__device__ inline void ext_leaf_test(SceneRef sc, int idx, bool box, const Path<double> &P, double tmin, ExtHit &H) {
+    const double2 *q = reinterpret_cast<const double2 *>(sc.leaf_rec + (size_t)idx * RTMI_LEAF_REC_DOUBLES);
+    const int4 hdr = *reinterpret_cast<const int4 *>(q);
+    const double2 q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+    if (hdr.y) { ext_prim_test<false>(sc, idx, P, tmin, H); return; } // (rare kinds, long chains)
+    LocalRay r = {P.ox, P.oy, P.oz, P.dx, P.dy, P.dz};
+    if (hdr.z | hdr.w) { // (skipped by a wave whose leaves carry no instance chain)
+        leaf_xform(hdr.z, q3.y, q4.x, q4.y, r);
+        leaf_xform(hdr.w, q5.x, q5.y, q6.x, r);
+    }
+    const double g0 = q1.x, g1 = q1.y, g2 = q2.x, g3 = q2.y, g4 = q3.x;
+    if (box) { ext_box_faces(r, g0, g1, g2, g3, g4, q6.y, tmin, idx, H); return; }
+    const int kind = hdr.x;
+    if (kind <= RTMI_PRIM_UVSPHERE) {
+        Prim4<double> s;
+        s.cx = g0; s.cy = g1; s.cz = g2; s.r2 = g3;
+        Path<double> L; L.ox = r.ox; L.oy = r.oy; L.oz = r.oz; L.dx = r.dx; L.dy = r.dy; L.dz = r.dz;
+        const double a = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
+        double bq, cq, disc;
+        sphere_test(s, L, a, bq, cq, disc);
+        if (disc >= 0.0 && !(tmin >= 0.0 && bq > 0.0 && cq > 0.0)) {
+            const double sq = rt_sqrt(disc);
+            double t = (-bq - sq) / a;
+            if (!(t > tmin)) t = (-bq + sq) / a;
+            if (t > tmin) ext_update(H, t, idx, false);
+        }
+    } else { // a rectangle: plane axis a, in-plane axes u, v
+        int ax, ua, va;
+        rect_axes(kind, ax, ua, va);
+        const double oa = pick3(ax, r.ox, r.oy, r.oz), da = pick3(ax, r.dx, r.dy, r.dz);
+        const double t = (g4 - oa) / da;
+        if (t >= tmin) {
+            const double x = pick3(ua, r.ox, r.oy, r.oz) + t * pick3(ua, r.dx, r.dy, r.dz), y = pick3(va, r.ox, r.oy, r.oz) + t * pick3(va, r.dx, r.dy, r.dz);
+            if (x >= g0 && x <= g2 && y >= g1 && y <= g3) ext_update(H, t, idx, true);
+        }
+    }
+}
+
 // the flat scan (FP32 cull + exact test) over all primitives
 // [lo, hi): only the primitives of this index range (RTMI_MEDIA_HITLIST scans the list in pieces, between its media); default: all
 __device__ inline void scan_all_cull_ext(SceneRef sc, const Path<double> &P, double a, double tmin, ExtHit &H, int lo = 0, int hi = 0x7fffffff) {
@@ -1656,8 +1746,13 @@ __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> 
     auto leaf = [&](int code) { // one primitive, or the six faces of a Box (RTMI_LEAF_BOX: one chain, one local ray, three divisors)
         const int bits = ~code, idx = bits & 0x1fffffff;
         if (idx >= lo && idx < hi) {
-            if (bits & RTMI_LEAF_BOX) { if (COUNT) cnt[1] += 5; ext_box_test<false>(sc, idx, P, tmin, H); }
+            if (COUNT && (bits & RTMI_LEAF_BOX)) cnt[1] += 5;
+#if RTMI_LEAF_RECORDS
+            ext_leaf_test(sc, idx, (bits & RTMI_LEAF_BOX) != 0, P, tmin, H);
+#else
+            if (bits & RTMI_LEAF_BOX) ext_box_test<false>(sc, idx, P, tmin, H);
             else ext_prim_test<false>(sc, idx, P, tmin, H);
+#endif
         }
     };
     auto best = [&]() { return ext_best_hi(H); };
