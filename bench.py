@@ -111,14 +111,27 @@ def cpu_baseline(scene, flat, nx, ny, ns, budget_s=15.0):
                       "walking the reference's own bvh-node tree, not the JVM" % (len(rows), nx, ny, ns, samples, dt)}
 
 
+def fp_flops(classes, lanes_active, launch_s, share=1.0):
+    """executed floating-point work of one launch from the PMC instruction classes: wave-instructions x 64 lanes x the share of lanes that are live
+    (an FMA counts two operations); FP64 against the 78.6 TFLOP/s vector peak, FP32 against 157.3"""
+    if not classes or not lanes_active or launch_s <= 0:
+        return None
+    f64 = (2.0 * classes.get("FMA_F64", 0.0) + classes.get("ADD_F64", 0.0) + classes.get("MUL_F64", 0.0) + classes.get("TRANS_F64", 0.0)) * share
+    f32 = (2.0 * classes.get("FMA_F32", 0.0) + classes.get("ADD_F32", 0.0) + classes.get("MUL_F32", 0.0) + classes.get("TRANS_F32", 0.0)) * share
+    t64, t32 = f64 * 64.0 * lanes_active / launch_s / 1e12, f32 * 64.0 * lanes_active / launch_s / 1e12
+    return {"fp64_tflops": round(t64, 2), "fp32_tflops": round(t32, 2), "fp64_peak": FP64_PEAK_TFLOPS, "fp32_peak": FP32_PEAK_TFLOPS,
+            "frac": round(t64 / FP64_PEAK_TFLOPS + t32 / FP32_PEAK_TFLOPS, 4)}
+
+
 def roofline(cfg, accel, precision, n_prims, launch_s, launches_per_step, counts, share=1.0):
-    """The dominant kernel (trace_kernel) priced per launch.  counts: per FRAME on this GPU {segments, samples, pixels,
+    """The dominant kernel (trace_kernel) priced per launch.  accel: the acceleration structure that RAN ("bvh" / "flat": a small mixed-kind scene is
+    scanned even when the tree was asked for) -- it names the kernel and keys the PMC profile.  counts: per FRAME on this GPU {segments, samples, pixels,
     aabb_tests, prim_tests} from the device counters (live, counting instantiation run outside the timed region).
     share: fraction of the profiled whole-frame instruction counts this GPU executes (1/N under the tile partition)."""
     per = 1.0 / max(1, launches_per_step)
     S, smp, pix = counts["segments"] * per, counts["samples"] * per, counts["pixels"]
     rec = 32 if precision == "f64" else 16
-    out = {"kernel": "trace_kernel<%s,%s>" % (precision, "BVH" if accel == "bvh" else "flat scan + FP32 cull"),
+    out = {"kernel": "trace_kernel<%s,%s>" % (precision, "BVH" if accel == "bvh" else "flat scan"),
            "launch_ms": round(launch_s * 1e3, 4), "launches_per_step": launches_per_step}
     scene_bytes = n_prims * (32.0 + 96.0 + 8.0) + 4096.0  # node record + exact record + (kind, material) per primitive, + materials / camera
     if accel == "bvh":
@@ -168,39 +181,79 @@ def roofline(cfg, accel, precision, n_prims, launch_s, launches_per_step, counts
             prices = json.load(open(os.path.join(ROOT, "profiles", "valu_prices.json")))["classes"]
         except (OSError, ValueError, KeyError):
             pass
+        # the hardware's own busy time: SQ_ACTIVE_INST_VALU counts 4-cycle quanta per wave instruction in flight -- the HEADLINE fraction
+        counter = prof["valu_active_quad_cycles"] * 4.0 * share / (SIMDS * launch_s * CLOCK_GHZ * 1e9) if prof.get("valu_active_quad_cycles") else None
         if classes and prices:
-            # calibrated: every PMC instruction class at the issue cost measured for it on this chip (scripts/ubench/valu_cost.hip at the
-            # kernel's 4 waves per SIMD), the instructions no class names at the price of their mix
+            # the priced model (a cross-check, never clamped): every PMC instruction class at the issue cost measured for it on this chip
+            # (scripts/ubench/valu_cost.hip at the kernel's 4 waves per SIMD), the instructions no class names at the price of their mix
             named = sum(classes.values())
             cnt = dict(classes, OTHER=max(0.0, prof["valu_total"] - named))
             cyc = {k: sum(cnt[c] * prices[c][k] for c in cnt) * share for k in ("price", "low", "high")}
-            ach = cyc["price"] / launch_s / 1e9
-            model = {"per_class_price_cycles": {c: prices[c]["price"] for c in cnt}, "instructions_per_launch": {c: round(cnt[c] * share) for c in cnt},
-                     "frac_low": round(cyc["low"] / launch_s / 1e9 / peak, 4), "frac_high": round(min(1.0, cyc["high"] / launch_s / 1e9 / peak), 4),
+            m_frac = cyc["price"] / launch_s / 1e9 / peak
+            model = {"frac": round(m_frac, 4), "frac_low": round(cyc["low"] / launch_s / 1e9 / peak, 4), "frac_high": round(cyc["high"] / launch_s / 1e9 / peak, 4),
+                     "per_class_price_cycles": {c: prices[c]["price"] for c in cnt}, "instructions_per_launch": {c: round(cnt[c] * share) for c in cnt},
                      "prices_source": "profiles/valu_prices.json <- profiles/round3_ubench_valu_cost.txt",
-                     "round2_model_frac": round((fp64 * 4.0 + other * 2.0) / launch_s / 1e9 / peak, 4)}
-            if prof.get("valu_active_quad_cycles"):  # the hardware's own busy time: SQ_ACTIVE_INST_VALU counts 4-cycle quanta per wave instruction in flight
-                model["sq_active_inst_valu_frac"] = round(prof["valu_active_quad_cycles"] * 4.0 * share / (SIMDS * launch_s * CLOCK_GHZ * 1e9), 4)
+                     "note": "sum over the PMC instruction classes of count x measured issue cost, over the SIMD-cycles of the launch; un-clamped: a value above 1 or "
+                             "more than a few per cent above the counter means the class prices (chiefly the un-named 'OTHER' mix) are too high, not that the chip "
+                             "ran faster than its clock"}
+            if counter:
+                model["over_counter"] = round(m_frac / counter, 4)
+                model["agrees_with_counter"] = bool(m_frac <= 1.0 and abs(m_frac / counter - 1.0) <= 0.08)
         else:  # profiles taken before round 3 hold no per-class counts: the FMA-calibrated two-price model (FP64 x 4, everything else x 2)
-            ach = (fp64 * 4.0 + other * 2.0) / launch_s / 1e9
-            model = {"note": "no per-class counts in this profile: FP64 x 4 + other x 2 cycles"}
-        out.update({"bound": "valu", "achieved": round(ach, 1), "peak": peak, "unit": "G SIMD issue-cycles/s", "frac": round(min(1.0, ach / peak), 4),
-                    "traffic": traffic, "issue_model": model,
-                    "lanes_active": prof.get("lanes_active"),
+            m_frac = (fp64 * 4.0 + other * 2.0) / launch_s / 1e9 / peak
+            model = {"frac": round(m_frac, 4), "note": "no per-class counts in this profile: FP64 x 4 + other x 2 cycles"}
+        frac = counter if counter is not None else m_frac
+        lanes = prof.get("lanes_active")
+        out.update({"bound": "valu", "achieved": round(frac * peak, 1), "peak": peak, "unit": "G SIMD issue-cycles/s", "frac": round(frac, 4),
+                    "frac_source": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time): the hardware counter" if counter is not None else "priced instruction classes (no SQ_ACTIVE_INST_VALU in this profile)",
+                    "traffic": traffic, "issue_model": model, "lanes_active": lanes,
+                    "useful_lane_frac": round(frac * lanes, 4) if lanes else None,
+                    "fp": fp_flops(classes, lanes, launch_s, share),
                     "counts": {"valu_instructions_per_launch": round(prof["valu_total"] * share), "fp64_instructions_per_launch": round(fp64),
                                "fetch_kb": prof["fetch_kb"], "write_kb": prof["write_kb"], "source": prof.get("source"),
                                "kernel_sha": prof.get("kernel_sha"), "stale": prof.get("kernel_sha") != sha,
                                "note": "rocprofv3 PMC counters of this workload's trace_kernel launch (deterministic per launch), imported from "
                                        "profiles/pmc_counters.json; launch_ms is measured live (HIP events on the launch stream)"},
-                    "note": "binding resource = VALU issue under per-lane traversal divergence: frac = (sum over the PMC instruction classes of count x "
-                            "measured issue cost) / (1024 SIMDs x 2.4 GHz x launch time); lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): "
-                            "the share of those issue slots whose lanes do work"})
+                    "note": "binding resource = VALU issue under per-lane traversal divergence.  frac = the share of the SIMDs' issue cycles in which a vector instruction was "
+                            "in flight (occupancy of the issue slots, NOT efficiency); lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = the share of those "
+                            "slots' lanes that are live; useful_lane_frac = frac x lanes_active = the share of the VALU lane-slot peak that executes anything; fp.frac = "
+                            "executed floating-point operations against the FP64 / FP32 vector peaks (the rest of the issued instructions are integer, selects, compares, moves)"})
+        out["fp_frac"] = out["fp"]["frac"] if out.get("fp") else None
         out["hbm"]["measured_traffic_gbs"] = round(traffic / launch_s / 1e9, 2)
         out["hbm"]["measured_traffic_frac"] = round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 5)
     else:
         out.update({"bound": "valu", "achieved": None, "peak": SIMDS * CLOCK_GHZ, "unit": "G SIMD issue-cycles/s", "frac": None, "traffic": None,
-                    "note": "no PMC profile of this workload under profiles/pmc_counters.json: only the algorithmic HBM figure is priced"})
+                    "note": "no PMC profile of this workload (%s/%s/%s) under profiles/pmc_counters.json: only the algorithmic HBM figure is priced" % (cfg, accel, precision)})
     return out
+
+
+def one_frame_host(r, flat, nx, ny, ns, precision, accel):
+    """What a host that renders ONE frame per process pays (core.clj:73-113: -main builds the scene, renders it once, saves it): scene creation (records, the
+    device's tree and entry grid, upload) + one frame through the host entry rtmi_render (frame copied back), on a fresh context -- outside the timed region."""
+    from raytrace_clj_amd import core
+    import ctypes as C
+    ctx = core.Context(0)
+    ctx.set_option("accel", 1 if accel == "bvh" else 0)
+    ds0 = core.DeviceScene(flat, ctx=ctx)  # (first use of the context: lazy runtime initialisation stays out of the figures)
+    ds0.render(16, 16, 1)
+    ds0.close()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ds = core.DeviceScene(flat, ctx=ctx)
+        t1 = time.perf_counter()
+        ds.render(nx, ny, ns, precision=precision)
+        t2 = time.perf_counter()
+        nbytes = C.c_int64()
+        core.check(r._ffi.lib().rtmi_scene_device_bytes(ds.handle, C.byref(nbytes)))
+        ds.close()
+        cur = {"scene_create_ms": round((t1 - t0) * 1e3, 3), "first_frame_ms": round((t2 - t1) * 1e3, 3), "end_to_end_ms": round((t2 - t0) * 1e3, 3), "upload_bytes": int(nbytes.value)}
+        if best is None or cur["end_to_end_ms"] < best["end_to_end_ms"]:
+            best = cur
+    ctx.close()
+    best["note"] = ("one-frame host (core.clj:73-113): rtmi_scene_create_ex (flat records -> device tree + entry grid -> upload) + ONE frame through the host entry "
+                    "rtmi_render incl. the copy of the frame back over PCIe (the sample workspace already allocated); best of 3; not part of `value`")
+    return best
 
 
 def main():
@@ -242,12 +295,14 @@ def main():
     rehearsal = (multi_proc and os.environ.get("RTMI_BENCH_REHEARSAL") == "1") or (in_library and visible < world)
     if in_library and not rehearsal:
         os.environ["RTMI_MULTI_GATHER"] = "rccl"  # distinct devices: the gather is the in-library ncclGather or the run fails -- never silent peer copies
-    if multi_proc and rehearsal:
+    # RTMI_BENCH_SHARE_DEVICE=1 (test hook): a mis-launched job -- every rank binds device 0 -- that does NOT call itself a rehearsal: the line must refuse
+    share_dev = multi_proc and os.environ.get("RTMI_BENCH_SHARE_DEVICE") == "1"
+    if multi_proc and (rehearsal or share_dev):
         local_rank = 0
     torch.cuda.set_device(local_rank if multi_proc else 0)
     if multi_proc:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
+        if rehearsal or share_dev:
             dist.init_process_group("gloo", rank=rank, world_size=world)
             rdist.HOST_STAGED_GATHER = True
         else:
@@ -304,7 +359,9 @@ def main():
             return self.tr.last_gather_ms() if multi_proc else None
 
         def gather_path(self):
-            return ("host-staged gloo gather (rehearsal)" if rehearsal else "torch.distributed gather (backend nccl = RCCL)") if multi_proc else "none"
+            if not multi_proc:
+                return "none"
+            return "torch.distributed.gather, backend %s%s" % (dist.get_backend(), " (host-staged: rehearsal)" if rehearsal else (" = RCCL" if dist.get_backend() == "nccl" else ""))
 
     class InLibrary:  # one host process, N devices behind the C-ABI
         def __init__(self, flat, nx, ny):
@@ -325,7 +382,8 @@ def main():
 
         def trace_ms(self):
             per = self.md.last_trace_ms()
-            return per[0]  # replica 0's launches (the roofline prices one GPU's kernel)
+            self.per_replica = per  # every replica's (ms, launches) of the window: the line reports min / max, the roofline prices the slowest
+            return max(per, key=lambda x: x[0])
 
         def reduce_ms(self):
             return self.md.ctxs[0].last_reduce_ms()
@@ -359,14 +417,16 @@ def main():
             drv.step(ns)
         barrier()
         dt = time.perf_counter() - t0
+        dt_local = dt
         trace_ms, launches = drv.trace_ms()
+        per_replica = list(getattr(drv, "per_replica", None) or [])  # in-library form: every replica's (ms, launches) of the timed window
         reduce_ms, reduce_launches = drv.reduce_ms()
         gather_ms = drv.gather_ms() if world > 1 else None
         seg_local, pix_local = drv.counters()
         accel_ran = drv.accel_ran()  # small mixed-kind scenes answer a request for the tree with the scan (option flat_below)
         segments = seg_local
         if multi_proc:
-            coll_dev = "cpu" if rehearsal else "cuda"
+            coll_dev = "cpu" if (rehearsal or share_dev) else "cuda"
             t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -388,7 +448,9 @@ def main():
         launch_s = trace_ms / 1e3 / max(1, launches)
         res = {"value": round(samples / (dt / steps) / 1e6, 3), "ms_per_step": round(dt / steps * 1e3, 4), "segments": segments,
                "segments_per_sample": round(segments / samples, 4), "accel_ran": accel_ran,
-               "roofline": roofline(cfg_name, accel, args.precision, n_prims, launch_s, launches_per_step, counts, share=1.0 / world)}
+               "roofline": roofline(cfg_name, accel_ran, args.precision, n_prims, launch_s, launches_per_step, counts, share=1.0 / world),
+               "trace_ms_per_step": round(trace_ms / max(1, steps), 4), "dt_local_ms": round(dt_local / steps * 1e3, 4), "segments_local": seg_local,
+               "per_replica": per_replica}
         if reduce_launches:  # the one HBM-bound kernel of the path: the in-order per-pixel sample reduction (core.clj:52-53)
             red_s = reduce_ms / 1e3 / reduce_launches
             red_bytes = (counts["samples"] * 24.0 + counts["pixels"] * 24.0 * (2 * launches_per_step - 1)) / launches_per_step  # samples read once; running sums written / re-read between passes
@@ -408,6 +470,36 @@ def main():
     drv = InLibrary(flat, nx, ny) if in_library else OneGpu(flat, nx, ny, max(1, args.frames_in_flight) if world == 1 else 1)
     res = measure(drv, args.accel, args.steps, args.warmup, cfg, nx, ny, ns, n_prims)
 
+    # ---- N > 1, one process per GPU: a line that proves what ran -- every rank reports its device, its own kernel time, segments and tiles --------------
+    ranks_info = None
+    if multi_proc:
+        from raytrace_clj_amd import dist as rd
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        ident = str(getattr(props, "uuid", "") or "") or str(getattr(props, "pci_bus_id", "") or "")
+        if hasattr(props, "pci_bus_id"):
+            ident = "%s pci %04x:%02x:%02x" % (ident, getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0))
+        mine = {"rank": rank, "device_index": int(torch.cuda.current_device()), "device": ident.strip(), "device_name": props.name,
+                "trace_ms": res["trace_ms_per_step"], "step_ms": res["dt_local_ms"], "segments": int(res["segments_local"]),
+                "tiles": len(rd.local_tile_ids(nx, ny, rank, world)), "gather_ms": res.get("gather_ms")}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        tr = [e["trace_ms"] for e in everyone]
+        sg = [e["segments"] for e in everyone]
+        devices = [e["device"] or ("index %d" % e["device_index"]) for e in everyone]
+        distinct = len(set(devices)) == world
+        ranks_info = {"n": dist.get_world_size(), "backend": dist.get_backend(), "per_rank": everyone, "distinct_devices": distinct,
+                      "trace_ms_min": round(min(tr), 4), "trace_ms_max": round(max(tr), 4),
+                      "imbalance": round(max(tr) / (sum(tr) / len(tr)), 4) if sum(tr) > 0 else None,
+                      "segments_imbalance": round(max(sg) / (sum(sg) / len(sg)), 4) if sum(sg) > 0 else None,
+                      "gather_bytes": int((world - 1) * rd.tiles_per_rank(nx, ny, world) * 64 * 3 * 8),
+                      "note": "imbalance = slowest rank's trace-kernel time per step / the mean over ranks; gather_bytes = what arrives at rank 0 per frame "
+                              "(world - 1 records of tiles_per_rank x 64 x 3 doubles); gather_ms (top level) = rank 0's gather interval = transfer + wait for the slowest rank"}
+        if not distinct and not rehearsal:
+            if rank == 0:
+                print(json.dumps({"error": "two ranks report the same device", "ranks": ranks_info}), flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
     out = None
     if rank == 0:
         out = {
@@ -423,6 +515,14 @@ def main():
         for k in ("aabb_tests_per_segment", "prim_tests_per_segment", "gather_ms", "gather_path"):
             if k in res:
                 out[k] = res[k]
+        if in_library:  # every replica's launches, not replica 0's
+            per = res.get("per_replica") or []
+            ms = [a / max(1, args.steps) for a, b in per]  # ms of trace kernel per step, per replica
+            out["replicas"] = {"n": world, "devices": [i % visible for i in range(world)], "trace_ms_per_step": [round(x, 4) for x in ms],
+                               "trace_ms_min": round(min(ms), 4) if ms else None, "trace_ms_max": round(max(ms), 4) if ms else None,
+                               "imbalance": round(max(ms) / (sum(ms) / len(ms)), 4) if ms and sum(ms) > 0 else None}
+        if multi_proc:
+            out["ranks"] = ranks_info
         if world > 1:
             out["config"]["scaling_note"] = ("strong scaling of BASELINE configs[3] (the frame is fixed, its 8x8 tiles are dealt round-robin over the GPUs); the "
                                              "N = 1 point of this curve is the 'c4' key of the `--gpus 1` line (same frame on one GPU), not that line's C3 value")
@@ -456,6 +556,13 @@ def main():
             o = measure(drv, other_accel, max(2, min(args.steps, 5)), 1, cfg, nx, ny, ns, n_prims)
             out["other_accel"] = {"accel": other_accel, "value": o["value"], "ms_per_step": o["ms_per_step"], "roofline": o["roofline"]}
     if rank == 0:
+        if world == 1:  # section 8(d): scene upload reported separately and included in an end-to-end figure
+            drv_close = getattr(getattr(drv, "pl", None), "close", None)
+            if drv_close:
+                drv_close()  # release the timed driver's workspace first: the one-frame host allocates its own
+            e2e = one_frame_host(r, flat, nx, ny, ns, args.precision, args.accel)
+            out["scene_create_ms"], out["upload_bytes"], out["end_to_end_ms"] = e2e["scene_create_ms"], e2e["upload_bytes"], e2e["end_to_end_ms"]
+            out["one_frame_host"] = e2e
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, flat, nx, ny, ns)
         print(json.dumps(out), flush=True)

@@ -159,6 +159,8 @@ int rtmi_scene_set_media_calls(rtmi_scene *scene, int32_t n_calls, const int32_t
  * A world that mixes the two (a Hitlist holding media below a bvh-node) is not supported: the flatteners raise "unsupported on GPU path". */
 enum { RTMI_MEDIA_DESCENT = 0, RTMI_MEDIA_HITLIST = 1 };
 int rtmi_scene_set_media_mode(rtmi_scene *scene, int32_t mode);
+/* HBM bytes the scene occupies (everything its creation uploaded: records, tree, tables) -- bench.py's `upload_bytes` */
+int rtmi_scene_device_bytes(rtmi_scene *scene, int64_t *out_bytes);
 int rtmi_scene_destroy(rtmi_scene *scene);
 
 /* ---- the hot path --------------------------------------------------------------------------- */
@@ -292,6 +294,14 @@ int rtmi_probe_arith(rtmi_ctx *ctx, int32_t n, const double *abc, double *out);
 #define RTMI_PROBE_MATH_SLOTS 12
 int rtmi_probe_math2(rtmi_ctx *ctx, int32_t n, const double *abc, double tmin, double tmax, int32_t n_slots, double *out);
 int rtmi_probe_math(rtmi_ctx *ctx, int32_t n, const double *abc, double tmin, double tmax, double *out);
+
+/* test hook, host arithmetic only (no device): the IEEE half (bits) at or beyond x in the given direction -- what the tree's half-plane node records are
+ * rounded with (up != 0: the smallest half >= x, else the largest half <= x; +-inf beyond the half range) */
+int rtmi_test_build_tree(int32_t n, const double *geom, const double *cam, int32_t threads, uint64_t *out_hash, int32_t *out_info, double *out_ms);
+/* ^ test hook, host code only: the device's tree and entry grid over n spheres (geom[n][4] = cx cy cz r) exactly as rtmi_scene_create builds them -- on the
+ * library's team of build threads, or with threads = 1 on the calling thread alone; out_hash = FNV-1a of the node array and the grid's root codes (the same
+ * for any thread count), out_info[4] = node records, depth, grid cells per side, big primitives; out_ms = the build's wall time */
+int rtmi_test_half_outward(double x, int32_t up); /* x: a float value (host scalars are doubles at this boundary) */
 
 #ifdef __cplusplus
 }

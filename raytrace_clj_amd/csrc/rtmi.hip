@@ -14,6 +14,11 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <thread>
 #include <cmath>
 #include <cmath>
 #include <cstdarg>
@@ -158,19 +163,25 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
         if (best_i >= 0) best_t = H.t;
         return;
     }
+    // Media FIRST (RTMI_MEDIA_DESCENT: every medium's hit? sees the caller's un-narrowed interval, hitable.clj:99-105, so its result -- and its draws, the only
+    // draws of a hit? -- do not depend on the surfaces; ExtHit folds candidates in any order).  The surfaces' traversal then starts with the closest MEDIUM hit as
+    // its bound: a path scattering inside make-final's subsurface sphere (mean free path 5; a third of that scene's segments) or ending in its haze no longer
+    // walks the tree with an unbounded interval before its medium is asked.  The reference's call order is kept: primitive-index order = the order its descent
+    // calls the media (and draws).  A resumed lane (time-sliced traversal) evaluated its media when its segment began; they ride in its parked hit state.
+    if (!(SLICED && bvh && *mid)) {
+        MediumChord chord; chord.idx = -1; chord.ok = false; chord.t1 = chord.t2 = chord.mag = 0.0;
+        for (int k = 0; k < sc.n_media; ++k) ext_medium_test(sc, sc.media_idx[k], P, tmin, tmax, H, chord, COUNT ? cnt : nullptr);
+        RTMI_PH(PH_LOOP) // (diagnostic build: the media are booked on the otherwise unused first phase)
+    }
     if (bvh) {
-        if (SLICED) { // time-sliced: a suspended lane's media are evaluated (and draw) when its traversal completes, as in the plain loop
+        if (SLICED) {
             const bool done = scan_bvh_ext<true, COUNT>(sc, stack, P, a, tmin, H, stack + susp_off, *mid, min_lanes, cnt);
             *mid = !done;
             if (!done) return;
         } else scan_bvh_ext<false, COUNT>(sc, stack, P, a, tmin, H, nullptr, false, 0, cnt);
     } else if (sc.small_scan) scan_small_ext(sc, P, tmin, H); // (wave-uniform)
     else scan_all_cull_ext(sc, P, a, tmin, H);
-    // media: after the surfaces, in primitive-index order = the order the reference's descent calls their hit? (and draws)
     RTMI_PH(PH_BVH_POST)
-    MediumChord chord; chord.idx = -1; chord.ok = false; chord.t1 = chord.t2 = chord.mag = 0.0;
-    for (int k = 0; k < sc.n_media; ++k) ext_medium_test(sc, sc.media_idx[k], P, tmin, tmax, H, chord, COUNT ? cnt : nullptr);
-    RTMI_PH(PH_LOOP) // (diagnostic build: the media are booked on the otherwise unused first phase)
     best_i = ext_winner(H);
     if (best_i >= 0) best_t = H.t;
 }
@@ -773,6 +784,7 @@ struct rtmi_ctx {
     int last_accel = -1;       // RTMI_ACCEL_* the most recent render ran (rtmi_last_accel): option "flat_below" can answer a request for the tree with the scan
     int last_passes = 0;       // sample passes of the most recent render (rtmi_last_passes)
     int last_grid = 0; // workgroups of the last trace launch (diagnostics)
+    std::map<std::pair<const void *, size_t>, int> occupancy; // resident workgroups per CU by (kernel, dynamic LDS bytes)
     std::vector<int> tile_ids_host;
     int tile_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
     std::vector<hipEvent_t> events_r; // RTMI_FLAG_TIMING: after the reduction that follows launch k
@@ -794,6 +806,7 @@ struct rtmi_scene {
     DevScene dev{};             // host copy of the descriptor
     ScenePtr d_dev = nullptr;   // the descriptor in HBM (what the kernels read)
     std::vector<void *> allocs;
+    size_t device_bytes = 0;  // HBM the scene occupies = what its creation uploads (rtmi_scene_device_bytes)
     int n_prims = 0, n_mats = 0, n_tex = 0;
     int bvh_node_count = 0;   // inner nodes of the device's tree
     int bvh_depth = 0;        // deepest leaf of the device's tree(s)
@@ -822,6 +835,7 @@ template <typename T> int upload(rtmi_scene *s, const std::vector<T> &v, const T
     const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
     if (hipMalloc(&p, bytes) != hipSuccess) return fail(RTMI_E_NOMEM, "hipMalloc(%zu) failed", bytes);
     s->allocs.push_back(p);
+    s->device_bytes += bytes;
     if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = reinterpret_cast<const T *>(p);
     return RTMI_OK;
@@ -1015,7 +1029,14 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         }
         // persistent launch: as many workgroups as stay resident (at most blocks_per_cu per CU); the queue feeds them
         int resident = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, kTraceBlock, dyn_lds));
+        { // the occupancy query is a runtime call per launch and replica: asked once per (kernel, LDS bytes) and kept on the context
+            const std::pair<const void *, size_t> key(reinterpret_cast<const void *>(kern), dyn_lds);
+            auto it = c->occupancy.find(key);
+            if (it == c->occupancy.end()) {
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, kTraceBlock, dyn_lds));
+                c->occupancy.emplace(key, resident);
+            } else resident = it->second;
+        }
         const int grid_trace = std::max(1, c->cus * std::max(1, std::min(c->blocks_per_cu * (256 / kTraceBlock), resident)));
         if (c->last_grid != grid_trace && std::getenv("RTMI_DEBUG"))
             fprintf(stderr, "[rtmi] trace launch: %d workgroups of %d threads (%d resident per CU by the occupancy query, cap %d), %zu B LDS each\n",
@@ -1093,13 +1114,74 @@ inline double box_area(const BvhBox &b) { const double x = b.hi[0] - b.lo[0], y 
 inline float f_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -INFINITY); return f; }
 inline float f_up(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, INFINITY); return f; }
 
+// Host-side scene preparation (the device's trees) runs on a small TEAM of threads created once per process and kept: on the GPU boxes of this pool creating a
+// thread costs ~0.3 ms, a team of 16 per call cost more than the 11 025 rectangle trees it built.  run(fn): the caller and every worker execute fn() once.
+static std::atomic<int> g_build_single{0}; // test hook (rtmi_test_build_tree): build on the calling thread only
+inline unsigned team_size() {
+    unsigned n = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    if (const char *e = std::getenv("RTMI_BUILD_THREADS")) n = (unsigned)std::max(1, std::min(64, std::atoi(e)));
+    return n;
+}
+inline unsigned build_threads() { return g_build_single.load() ? 1u : team_size(); }
+class WorkTeam {
+    std::vector<std::thread> th;
+    std::mutex mu, use_mu;
+    std::condition_variable cv, done_cv;
+    const std::function<void()> *fn = nullptr;
+    unsigned long gen = 0;
+    unsigned pending = 0;
+    bool stop = false;
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void()> *f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen; f = fn;
+            }
+            (*f)();
+            { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) done_cv.notify_all(); }
+        }
+    }
+public:
+    explicit WorkTeam(unsigned n) { for (unsigned t = 1; t < n; ++t) th.emplace_back([this] { loop(); }); }
+    ~WorkTeam() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (std::thread &t : th) t.join(); }
+    static WorkTeam &get() { static WorkTeam team(team_size()); return team; }
+    void run(const std::function<void()> &f) {
+        std::unique_lock<std::mutex> use(use_mu, std::try_to_lock);
+        if (!use.owns_lock() || th.empty() || g_build_single.load()) { f(); return; } // the team is busy with another host thread's scene: this one builds alone
+        { std::lock_guard<std::mutex> lk(mu); fn = &f; pending = (unsigned)th.size(); ++gen; }
+        cv.notify_all();
+        f();
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return pending == 0; });
+    }
+};
+// fn(begin, end) over [0, n) in blocks taken from a shared counter; `first` (optional) is one more job some thread of the team takes before the blocks
+template <typename F> void parallel_blocks(size_t n, size_t block, F fn, const std::function<void()> *first = nullptr) {
+    std::atomic<size_t> next{0};
+    std::atomic<bool> first_taken{first == nullptr};
+    const std::function<void()> worker = [&]() {
+        if (!first_taken.exchange(true)) (*first)();
+        for (size_t b = next.fetch_add(block); b < n; b = next.fetch_add(block)) fn(b, std::min(n, b + block));
+    };
+    if (n < 4 * block && !first) { worker(); return; }
+    WorkTeam::get().run(worker);
+}
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct BvhBuilder {
     std::vector<BvhItem> items;
     std::vector<float> nodes; // 16 floats per node
     std::vector<char> moving; // by original primitive index
     std::vector<char> box6;   // by original primitive index: the first of six rectangles that form a Box (one leaf: RTMI_LEAF_BOX)
     double delta = 0.0;
-    int leaf_code(int idx) const { return ~(idx | (moving[(size_t)idx] ? 0x40000000 : 0) | (!box6.empty() && box6[(size_t)idx] ? RTMI_LEAF_BOX : 0)); }
+    const BvhBuilder *flags = nullptr; // a per-job builder (entry-grid rectangle trees) reads the flag vectors of the scene's builder instead of copying them
+    int leaf_code(int idx) const {
+        const BvhBuilder &f = flags ? *flags : *this;
+        return ~(idx | (f.moving[(size_t)idx] ? 0x40000000 : 0) | (!f.box6.empty() && f.box6[(size_t)idx] ? RTMI_LEAF_BOX : 0));
+    }
     int sah_depth = 8, max_depth = 0;
     double min_frac = 0.0;    // experiments: RTMI_BVH_MIN_FRAC = smallest share of a node's primitives a child may get (balance)
     int sweep_max = 0;  // subtrees up to this many primitives: exact sweep SAH; above: 32 bins (build time)
@@ -1166,22 +1248,28 @@ struct BvhBuilder {
             for (int ax = 0; ax < 3; ++ax) {
                 const double ext = chi[ax] - clo[ax];
                 if (!(ext > 0)) continue;
+                // Only OCCUPIED bins matter: between two occupied bins the two sides of a split -- boxes and counts -- do not change, so every split position of
+                // such a run costs the same and the strict `cost < best` keeps the run's first, which is the occupied bin itself.  Walking the occupied bins (at
+                // most e - b of them) instead of all 32 gives the same split for a fraction of the work on the small sets of the entry grid's rectangle trees
+                // (3 - 14 primitives each, 11 025 trees at C3).
                 BvhBox bb[NB]; int cnt[NB];
-                for (int k = 0; k < NB; ++k) { bb[k] = box_empty(); cnt[k] = 0; }
+                unsigned occ = 0;
                 for (int i = b; i < e; ++i) {
                     const int q = std::min(NB - 1, std::max(0, (int)((items[(size_t)i].cen[ax] - clo[ax]) / ext * NB)));
+                    if (!((occ >> q) & 1u)) { bb[q] = box_empty(); cnt[q] = 0; occ |= 1u << q; }
                     box_grow(bb[q], items[(size_t)i].b); cnt[q]++;
                 }
-                BvhBox right[NB]; int rc[NB];
+                int list[NB], m = 0;
+                for (int q = 0; q < NB; ++q) if ((occ >> q) & 1u) list[m++] = q;
+                BvhBox right[NB]; int rc[NB]; // right[j] / rc[j]: the occupied bins list[j], list[j + 1], ...
                 BvhBox acc = box_empty(); int n = 0;
-                for (int k = NB - 1; k > 0; --k) { box_grow(acc, bb[k]); n += cnt[k]; right[k] = acc; rc[k] = n; }
+                for (int j = m - 1; j > 0; --j) { box_grow(acc, bb[list[j]]); n += cnt[list[j]]; right[j] = acc; rc[j] = n; }
                 acc = box_empty(); n = 0;
-                for (int k = 0; k < NB - 1; ++k) {
-                    box_grow(acc, bb[k]); n += cnt[k];
-                    if (n == 0 || rc[k + 1] == 0) continue;
-                    if (std::min(n, rc[k + 1]) < min_frac * (e - b)) continue;
-                    const double cost = box_area(acc) * n + box_area(right[k + 1]) * rc[k + 1];
-                    if (cost < best) { best = cost; best_k = k; best_axis = ax; }
+                for (int j = 0; j + 1 < m; ++j) { // split after bin k = list[j]
+                    box_grow(acc, bb[list[j]]); n += cnt[list[j]];
+                    if (std::min(n, rc[j + 1]) < min_frac * (e - b)) continue;
+                    const double cost = box_area(acc) * n + box_area(right[j + 1]) * rc[j + 1];
+                    if (cost < best) { best = cost; best_k = list[j]; best_axis = ax; }
                 }
             }
             if (best_k >= 0) {
@@ -1233,6 +1321,19 @@ bool prim_world_box(int kind, const double *g, const int32_t *xf_kind, const dou
     } else {
         for (int k = 0; k < 3; ++k) { b.lo[k] = std::min(g[k], std::min(g[3 + k], g[6 + k])); b.hi[k] = std::max(g[k], std::max(g[3 + k], g[6 + k])); }
     }
+    if ((kind == RTMI_PRIM_SPHERE || kind == RTMI_PRIM_UVSPHERE) && xf_count > 0) {
+        // A sphere under Translate / RotateY wrappers is a sphere of the same radius about the mapped centre: its world box is centre +- r, not the box of the
+        // eight rotated corners of its local box (a RotateY of 15 degrees grows that one by a fifth per side -- half again the area -- and make-final's
+        // thousand spheres sit behind one).  The wrappers' own rounding moves a hit point by ~1e-13 of a coordinate; the slack below and the tree's 2^-21 obound cover it.
+        double c[3] = {g[0], g[1], g[2]};
+        const double r = std::fabs(g[3]);
+        for (int q = xf_count - 1; q >= 0; --q) {
+            const double *p = xf_param + (size_t)(xf_first + q) * 3;
+            if (xf_kind[xf_first + q] == RTMI_XFORM_TRANSLATE) { c[0] += p[0]; c[1] += p[1]; c[2] += p[2]; }
+            else { const double sn = p[0], cs = p[1]; const double rx = cs * c[0] + sn * c[2], rz = -(sn * c[0]) + cs * c[2]; c[0] = rx; c[2] = rz; }
+        }
+        for (int k = 0; k < 3; ++k) { const double pad = 1e-9 * (std::fabs(c[k]) + r) + 1e-12; b.lo[k] = c[k] - r - pad; b.hi[k] = c[k] + r + pad; }
+    } else
     for (int q = xf_count - 1; q >= 0; --q) {
         const double *p = xf_param + (size_t)(xf_first + q) * 3;
         BvhBox nb = box_empty();
@@ -1254,22 +1355,27 @@ bool prim_world_box(int kind, const double *g, const int32_t *xf_kind, const dou
     return true;
 }
 
-// the IEEE half at or beyond x in the given direction (up: >= x, else <= x); beyond the half range: +-inf
+// the IEEE half at or beyond x in the given direction (up: >= x, else <= x); beyond the half range: +-inf.  Integer arithmetic on the float's bits (directed
+// rounding of the magnitude: toward zero by truncation, away from zero by truncation + 1 when inexact): a host without F16C converts _Float16 in software, and a
+// scene's tree has twelve planes per node (C3: 1.4 million conversions there and back).  rtmi_test_half_outward exposes it to the CPU test against numpy.
 static uint16_t half_outward(float x, bool up) {
-    _Float16 h = (_Float16)x;
-    uint16_t b; std::memcpy(&b, &h, 2);
-    const float back = (float)h;
-    if (up ? (back < x) : (back > x)) { // step to the next half outward
-        if (b == 0x0000 || b == 0x8000) b = up ? 0x0001 : 0x8001;
-        else if ((b & 0x8000) ? !up : up) b += 1; // away from zero
-        else b -= 1;                               // towards zero
-    }
-    return b;
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    const uint32_t sign = u >> 31, a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(0x7e00u | (sign << 15)); // NaN
+    const bool away = up != (sign != 0); // the magnitude rounds away from zero
+    uint32_t m;
+    bool inexact;
+    if (a >= 0x47800000u) { m = a == 0x7f800000u ? 0x7c00u : 0x7bffu; inexact = a != 0x7f800000u; } // >= 2^16: the largest half (65504) toward zero, inf away
+    else if (a >= 0x38800000u) { m = (((a >> 23) - 112u) << 10) | ((a & 0x7fffffu) >> 13); inexact = (a & 0x1fffu) != 0; } // normal halves: 2^-14 <= |x| < 2^16
+    else { const float sc = std::fabs(x) * 16777216.0f; m = (uint32_t)sc; inexact = (float)m != sc; } // half subnormals: units of 2^-24 (the scaling is exact)
+    if (inexact && away) m += 1; // (carries into the exponent: 0x03ff + 1 = the smallest normal, 0x7bff + 1 = inf)
+    return (uint16_t)(m | (sign << 15));
 }
 // fills d.bvh_* ; returns the node array to upload.  wbox[i] / bounded[i]: prim_world_box of every primitive.
 // box_first[i] != 0: primitives i .. i + 5 are the six faces of one Box (detected at scene creation) -- one leaf, unless the box is too large for the tree
 std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, const std::vector<BvhBox> &wbox, const std::vector<char> &bounded, const double *cam,
-                             bool want_grid, std::vector<int> &grid_cells, const std::vector<char> &box_first, int *out_depth = nullptr) {
+                             bool want_grid, std::vector<int> &grid_cells, const std::vector<char> &box_first, int *out_depth = nullptr, const std::vector<BvhBox> *media_boxes = nullptr) {
     BvhBuilder B;
     struct DepthOut { BvhBuilder &b; int *o; ~DepthOut() { if (o) *o = b.max_depth; } } depth_out{B, out_depth};
     std::vector<BvhItem> all;
@@ -1315,6 +1421,8 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
     double cbound = 0.0;
     for (const BvhItem &it : B.items) for (int k = 0; k < 3; ++k) cbound = std::max(cbound, std::max(std::fabs(it.b.lo[k]), std::fabs(it.b.hi[k])));
     d.bvh_cbound = f_up(cbound);
+    std::vector<BvhItem> grid_items;
+    std::function<void()> whole_job; // the whole tree's build, when it is deferred to run beside the grid's jobs
     if (B.items.empty()) d.bvh_root = RTMI_BVH_EMPTY;
     else if (B.items.size() == 1) { // a lone primitive: a node whose right child is an empty box
         B.nodes.assign(16, 0.0f);
@@ -1331,19 +1439,33 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
         if (const char *e = std::getenv("RTMI_BVH_MIN_FRAC")) B.min_frac = std::atof(e);
         B.sah_depth = RTMI_BVH_STACK - 2; // depth budget: a node at depth d over k primitives may use SAH while d + ceil(log2 k) + 1 < budget
         (void)lg;
-        d.bvh_root = B.build(0, (int)B.items.size(), 0);
-        if (B.max_depth >= RTMI_BVH_STACK - 1 || B.nodes.size() / 16 >= (1u << 25)) { // cannot happen by construction / node byte offsets are 31-bit
+        // The whole tree and the entry grid's rectangle trees are independent: when a grid will be tried, the whole tree is built on a thread of its own
+        // (into B.nodes, which the grid's jobs do not touch: they build into builders of their own and are appended after the join)
+        grid_items.assign(B.items.begin(), B.items.end()); // (build() reorders B.items: the grid works on a copy taken before)
+        auto build_whole = [&B, &d]() {
+            const double tb0 = now_ms();
+            d.bvh_root = B.build(0, (int)B.items.size(), 0);
+            if (std::getenv("RTMI_DEBUG")) fprintf(stderr, "[rtmi] build: whole tree over %zu primitives %.2f ms\n", B.items.size(), now_ms() - tb0);
+        };
+        if (want_grid && B.items.size() >= 256 && build_threads() > 1) whole_job = build_whole; // deferred: the team's first job, beside the grid's rectangle trees
+        else build_whole();
+    }
+    auto join_whole = [&]() {
+        if (whole_job) { whole_job(); whole_job = nullptr; } // (no grid was built after all: build it here)
+        if (d.bvh_root >= 0 && (B.max_depth >= RTMI_BVH_STACK - 1 || B.nodes.size() / 16 >= (1u << 25))) { // cannot happen by construction / node byte offsets are 31-bit
             d.bvh_root = RTMI_BVH_EMPTY; d.n_big = 0; d.bvh_obound = -1.0f; // obound < 0: every ray takes the exact flat scan
             B.nodes.clear();
         }
-    }
+    };
     // ---- entry grid: a BVH per x-z cell over the primitives whose boxes overlap the cell (DevScene::grid_*) -------------------------------------
     d.grid_n = 0; d.grid_tall = RTMI_BVH_EMPTY; d.grid_kmax = 4; d.grid_walk = 0;
     grid_cells.clear();
     const char *grid_env = std::getenv("RTMI_GRID"); // "0": off; "n": n x n cells (experiments)
-    if (want_grid && d.bvh_root >= 0 && !(grid_env && grid_env[0] == '0') && B.items.size() >= 256) {
-        const size_t n_items = B.items.size();
-        std::vector<BvhItem> world(B.items.begin(), B.items.begin() + (long)n_items); // (build() has reordered them; any order will do)
+    const double tg0 = now_ms();
+    struct GridTimer { double t0; ~GridTimer() { if (std::getenv("RTMI_DEBUG")) fprintf(stderr, "[rtmi] build: entry grid + node formats %.2f ms\n", now_ms() - t0); } } grid_timer{tg0};
+    if (want_grid && !(grid_env && grid_env[0] == '0') && grid_items.size() >= 256) { // (the whole tree may still be in the making: nothing below touches B.nodes / B.items before join_whole())
+        const size_t n_items = grid_items.size();
+        const std::vector<BvhItem> &world = grid_items; // (any order will do)
         // the layer: every primitive except the few much taller than the typical one (the cover scene's three big spheres among 10 000 small ones)
         std::vector<double> hts(n_items);
         for (size_t i = 0; i < n_items; ++i) hts[i] = world[i].b.hi[1] - world[i].b.lo[1];
@@ -1399,20 +1521,65 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
             // grid_cells[(wi + 2 wj) G G + j0 G + i0]) -- over the union of the cells' primitives: a segment starts at ONE root (no root per cell to push and
             // to visit), and a primitive two cells of the rectangle share is in the tree once (it used to be tested exactly once per cell).
             if (!cell_items.empty()) grid_cells.assign((size_t)4 * G * G, RTMI_BVH_EMPTY);
-            std::vector<BvhItem> tmp;
-            std::vector<int> uni;
-            for (int fam = 0; fam < 4 && !cell_items.empty(); ++fam) {
-                const int wi = fam & 1, wj = fam >> 1;
-                for (int j = 0; j + wj < G; ++j) for (int i = 0; i + wi < G; ++i) {
-                    uni.clear();
+            // The 4 G^2 rectangle trees (C3: 11 025 of them) are independent: every job builds its tree in a builder of its own, worker threads take jobs from a
+            // shared counter, and the results are appended to the node array IN JOB ORDER with their node offsets rebased -- the same array whatever the thread
+            // count (scene creation at C3: 59 ms single-threaded, most of it here).
+            if (!cell_items.empty()) {
+                struct RectTree { std::vector<float> nodes; int root = RTMI_BVH_EMPTY; int depth = 0; };
+                const size_t n_jobs = (size_t)4 * G * G;
+                std::vector<RectTree> trees(n_jobs);
+                auto job = [&](size_t jb) {
+                    const int fam = (int)(jb / ((size_t)G * G)), j = (int)((jb / (size_t)G) % (size_t)G), i = (int)(jb % (size_t)G);
+                    const int wi = fam & 1, wj = fam >> 1;
+                    if (j + wj >= G || i + wi >= G) return;
+                    std::vector<int> uni;
                     for (int dj = 0; dj <= wj; ++dj) for (int di = 0; di <= wi; ++di) { const std::vector<int> &ci = cell_items[(size_t)(j + dj) * G + i + di]; uni.insert(uni.end(), ci.begin(), ci.end()); }
                     std::sort(uni.begin(), uni.end());
                     uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
-                    tmp.clear();
-                    for (int k : uni) tmp.push_back(layer[(size_t)k]);
-                    grid_cells[(size_t)fam * G * G + (size_t)j * G + i] = subtree(tmp);
+                    if (uni.empty()) return;
+                    BvhBuilder L;
+                    L.flags = &B; L.delta = B.delta; L.sah_depth = B.sah_depth; L.min_frac = B.min_frac; L.sweep_max = B.sweep_max; L.sah_levels = B.sah_levels;
+                    for (int k : uni) L.items.push_back(layer[(size_t)k]);
+                    RectTree &T = trees[jb];
+                    if (L.items.size() == 1) { // a lone primitive: a node whose right child is an empty box (a bare leaf code would skip the box test)
+                        L.nodes.assign(16, 0.0f);
+                        L.put_box(0, 0, L.items[0].b);
+                        L.put_empty_box(0, 1);
+                        const int l = L.leaf_code(L.items[0].idx);
+                        std::memcpy(&L.nodes[12], &l, 4); std::memcpy(&L.nodes[13], &l, 4);
+                        T.root = 0; T.depth = depth0 + 1;
+                    } else { T.root = L.build(0, (int)L.items.size(), depth0); T.depth = L.max_depth; }
+                    T.nodes.swap(L.nodes);
+                };
+                const double tr0 = now_ms();
+                { // the whole tree (if deferred) is one more job of the same team
+                    const std::function<void()> first = whole_job;
+                    whole_job = nullptr;
+                    parallel_blocks(n_jobs, 16, [&](size_t b, size_t e) { for (size_t q = b; q < e; ++q) job(q); }, first ? &first : nullptr);
+                }
+                if (std::getenv("RTMI_DEBUG")) fprintf(stderr, "[rtmi] build: %zu rectangle trees on %u threads %.2f ms\n", n_jobs, build_threads(), now_ms() - tr0);
+                join_whole();
+                size_t total_nodes = B.nodes.size();
+                for (const RectTree &T : trees) total_nodes += T.nodes.size();
+                B.nodes.reserve(total_nodes + 1024);
+                for (size_t jb = 0; jb < n_jobs; ++jb) { // append in job order, node offsets rebased
+                    RectTree &T = trees[jb];
+                    B.max_depth = std::max(B.max_depth, T.depth);
+                    if (T.root == RTMI_BVH_EMPTY) continue;
+                    const int base = (int)(B.nodes.size() / 16) * 64;
+                    for (size_t nd = 0; nd < T.nodes.size() / 16; ++nd) {
+                        int c[2];
+                        std::memcpy(c, &T.nodes[nd * 16 + 12], 8);
+                        for (int k = 0; k < 2; ++k) if (c[k] >= 0) c[k] += base; // inner node: byte offset of its record (leaf codes and RTMI_BVH_EMPTY are negative)
+                        std::memcpy(&T.nodes[nd * 16 + 12], c, 8);
+                    }
+                    B.nodes.insert(B.nodes.end(), T.nodes.begin(), T.nodes.end());
+                    grid_cells[jb] = T.root + base;
+                    std::vector<float>().swap(T.nodes);
                 }
             }
+            join_whole();
+            if (d.bvh_root < 0) cell_items.clear(); // (the whole tree did not fit the stack: every ray takes the flat scan, no grid either)
             if (!cell_items.empty()) d.grid_tall = subtree(tall);
             if (cell_items.empty() || B.max_depth >= RTMI_BVH_STACK - 1 || B.nodes.size() / 16 >= (1u << 25)) { // too deep for the stack: no grid (the whole tree above stays valid)
                 grid_cells.clear(); d.grid_tall = RTMI_BVH_EMPTY;
@@ -1435,39 +1602,91 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
             }
         }
     }
+    join_whole();
+    // ---- neighbourhood trees of the media (DevScene::mloc_*) ------------------------------------------------------------------------------------------------
+    d.n_mloc = 0;
+    // (measured on make-final: node visits per segment 10.2 -> 8.3, frame 17.43 vs 17.46 ms -- the segments it shortens finish early and wait for their wave's
+    // long ones; off unless RTMI_MLOC=1)
+    const char *mloc_env = std::getenv("RTMI_MLOC");
+    if (media_boxes && d.bvh_root >= 0 && mloc_env && mloc_env[0] == '1') {
+        const size_t n_tree = B.items.size(); // (the grid is never built for a scene with media: the items are the whole tree's)
+        std::vector<BvhItem> world(B.items.begin(), B.items.end());
+        for (const BvhBox &mb : *media_boxes) {
+            if (d.n_mloc >= 4) break;
+            BvhBox R = mb; // the boundary's box, a hundredth larger per side
+            for (int k = 0; k < 3; ++k) { const double pad = 0.01 * (mb.hi[k] - mb.lo[k]) + 4.0 * B.delta; R.lo[k] -= pad; R.hi[k] += pad; }
+            std::vector<BvhItem> its;
+            for (const BvhItem &it : world) { // every primitive with a surface point inside R: its box (the tree inflates it by delta once more) reaches into R
+                bool hit = true;
+                for (int k = 0; k < 3; ++k) hit = hit && it.b.hi[k] + 2.0 * B.delta >= R.lo[k] && it.b.lo[k] - 2.0 * B.delta <= R.hi[k];
+                if (hit) its.push_back(it);
+            }
+            if (its.size() * 2 > n_tree) continue; // a medium that holds most of the scene (make-final's haze): nothing to gain
+            int root = RTMI_BVH_EMPTY;
+            if (its.size() == 1) { // a lone primitive: a node whose right child is an empty box
+                const int node = (int)(B.nodes.size() / 16);
+                B.nodes.resize(B.nodes.size() + 16, 0.0f);
+                B.put_box(node, 0, its[0].b);
+                B.put_empty_box(node, 1);
+                const int l = B.leaf_code(its[0].idx);
+                std::memcpy(&B.nodes[(size_t)node * 16 + 12], &l, 4); std::memcpy(&B.nodes[(size_t)node * 16 + 13], &l, 4);
+                root = node * 64;
+            } else if (!its.empty()) {
+                const int b0 = (int)B.items.size();
+                B.items.insert(B.items.end(), its.begin(), its.end());
+                root = B.build(b0, b0 + (int)its.size(), 1);
+            }
+            if (B.max_depth >= RTMI_BVH_STACK - 1 || B.nodes.size() / 16 >= (1u << 25)) break; // (cannot happen: a subset of a tree that fitted)
+            d.mloc_root[d.n_mloc] = root;
+            for (int k = 0; k < 3; ++k) { d.mloc_box[d.n_mloc][k] = f_up(R.lo[k]); d.mloc_box[d.n_mloc][3 + k] = f_down(R.hi[k]); }
+            d.n_mloc++;
+        }
+    }
     d.bvh_node16 = 0;
     if (d.bvh_root != RTMI_BVH_EMPTY) { // 32-byte records (Node16) when rounding the planes to half costs little: 12 halves + 2 child codes
         auto half_bits = [](float x, bool up) { return half_outward(x, up); };
-        auto half_val = [](uint16_t b) { _Float16 h; std::memcpy(&h, &b, 2); return (double)(float)h; };
+        auto half_val = [](uint16_t b) { // the half's value (integer decode: no software _Float16 conversion)
+            const int e = (b >> 10) & 31, m = b & 1023;
+            const double v = e == 0 ? std::ldexp((double)m, -24) : (e == 31 ? (m ? (double)NAN : (double)INFINITY) : std::ldexp((double)(1024 + m), e - 25));
+            return (b >> 15) ? -v : v;
+        };
         std::vector<float> out(B.nodes.size() / 2, 0.0f);
         double area32 = 0.0, area16 = 0.0;
-        for (size_t n = 0; n < B.nodes.size() / 16; ++n) {
-            const float *q = &B.nodes[n * 16];
-            uint16_t h[12];
-            for (int side = 0; side < 2; ++side) {
-                const float lo[3] = {q[side * 4], q[side * 4 + 1], q[8 + side * 2]}, hi[3] = {q[side * 4 + 2], q[side * 4 + 3], q[8 + side * 2 + 1]};
-                double e32[3], e16[3];
-                for (int k = 0; k < 3; ++k) {
-                    h[side * 6 + k * 2] = half_bits(lo[k], false); h[side * 6 + k * 2 + 1] = half_bits(hi[k], true);
-                    e32[k] = (double)hi[k] - lo[k]; e16[k] = half_val(h[side * 6 + k * 2 + 1]) - half_val(h[side * 6 + k * 2]);
+        const size_t n_nodes = B.nodes.size() / 16;
+        std::vector<double> part32((n_nodes + 2047) / 2048 + 1, 0.0), part16(part32.size(), 0.0); // per block, summed in block order: the same sums whatever the thread count
+        parallel_blocks(n_nodes, 2048, [&](size_t nb, size_t ne) {
+            double a32 = 0.0, a16 = 0.0;
+            for (size_t n = nb; n < ne; ++n) {
+                const float *q = &B.nodes[n * 16];
+                uint16_t h[12];
+                for (int side = 0; side < 2; ++side) {
+                    const float lo[3] = {q[side * 4], q[side * 4 + 1], q[8 + side * 2]}, hi[3] = {q[side * 4 + 2], q[side * 4 + 3], q[8 + side * 2 + 1]};
+                    double e32[3], e16[3];
+                    for (int k = 0; k < 3; ++k) {
+                        h[side * 6 + k * 2] = half_bits(lo[k], false); h[side * 6 + k * 2 + 1] = half_bits(hi[k], true);
+                        e32[k] = (double)hi[k] - lo[k]; e16[k] = half_val(h[side * 6 + k * 2 + 1]) - half_val(h[side * 6 + k * 2]);
+                    }
+                    if (e32[0] >= 0 && std::isfinite(e32[0] + e32[1] + e32[2])) { // (the lone primitive's empty sibling is +inf / -inf)
+                        a32 += e32[0] * e32[1] + e32[1] * e32[2] + e32[2] * e32[0];
+                        a16 += std::isfinite(e16[0] + e16[1] + e16[2]) ? e16[0] * e16[1] + e16[1] * e16[2] + e16[2] * e16[0] : INFINITY;
+                    }
                 }
-                if (e32[0] >= 0 && std::isfinite(e32[0] + e32[1] + e32[2])) { // (the lone primitive's empty sibling is +inf / -inf)
-                    area32 += e32[0] * e32[1] + e32[1] * e32[2] + e32[2] * e32[0];
-                    area16 += std::isfinite(e16[0] + e16[1] + e16[2]) ? e16[0] * e16[1] + e16[1] * e16[2] + e16[2] * e16[0] : INFINITY;
-                }
+                int c[2];
+                std::memcpy(c, &q[12], 8);
+                for (int k = 0; k < 2; ++k) if (c[k] >= 0 && c[k] != RTMI_BVH_EMPTY) c[k] /= 2; // byte offsets of 32-byte records
+                std::memcpy(reinterpret_cast<char *>(&out[n * 8]), h, 24);
+                std::memcpy(reinterpret_cast<char *>(&out[n * 8]) + 24, c, 8);
             }
-            int c[2];
-            std::memcpy(c, &q[12], 8);
-            for (int k = 0; k < 2; ++k) if (c[k] >= 0 && c[k] != RTMI_BVH_EMPTY) c[k] /= 2; // byte offsets of 32-byte records
-            std::memcpy(reinterpret_cast<char *>(&out[n * 8]), h, 24);
-            std::memcpy(reinterpret_cast<char *>(&out[n * 8]) + 24, c, 8);
-        }
+            part32[nb / 2048] = a32; part16[nb / 2048] = a16;
+        });
+        for (size_t k = 0; k < part32.size(); ++k) { area32 += part32[k]; area16 += part16[k]; }
         const char *force = std::getenv("RTMI_NODE16"); // "0" / "1": override the choice (tests)
         const bool use16 = force ? force[0] == '1' : (area16 <= 1.25 * area32);
         if (use16) {
             d.bvh_node16 = 1;
             d.bvh_root = d.bvh_root >= 0 ? d.bvh_root / 2 : d.bvh_root;
             for (int &c : grid_cells) if (c >= 0) c /= 2;
+            for (int k = 0; k < d.n_mloc; ++k) if (d.mloc_root[k] >= 0) d.mloc_root[k] /= 2;
             if (d.grid_tall >= 0) d.grid_tall /= 2;
             return out;
         }
@@ -1489,6 +1708,35 @@ int check_render_args(rtmi_scene *s, int nx, int ny, int ns, int depth, int prec
 } // namespace
 
 // ---- library / context -------------------------------------------------------------------------------
+// test hook, host code only (no device): the device's tree (+ entry grid) over n spheres as rtmi_scene_create builds it, on the team or (threads = 1) on the
+// calling thread alone.  out_hash = FNV-1a of the node array and the grid's root codes, out_info = {node records, depth, grid cells per side, big primitives}
+RTMI_EXPORT int rtmi_test_build_tree(int32_t n, const double *geom, const double *cam, int32_t threads, uint64_t *out_hash, int32_t *out_info, double *out_ms) {
+    if (n <= 0 || !geom || !cam || !out_hash || !out_info || !out_ms) return fail(RTMI_E_ARG, "bad arguments");
+    std::vector<int> kind((size_t)n, RTMI_PRIM_SPHERE);
+    std::vector<BvhBox> wbox((size_t)n);
+    std::vector<char> bounded((size_t)n, 0), box_first((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        const double g[9] = {geom[4 * (size_t)i], geom[4 * (size_t)i + 1], geom[4 * (size_t)i + 2], geom[4 * (size_t)i + 3], 0, 0, 0, 0, 1};
+        bounded[(size_t)i] = prim_world_box(RTMI_PRIM_SPHERE, g, nullptr, nullptr, 0, 0, 0.0, 1.0, wbox[(size_t)i]);
+    }
+    DevScene d{};
+    std::vector<int> grid_cells;
+    int depth = 0;
+    g_build_single.store(threads == 1 ? 1 : 0);
+    const double t0 = now_ms();
+    const std::vector<float> nodes = build_bvh(d, n, kind.data(), wbox, bounded, cam, true, grid_cells, box_first, &depth);
+    *out_ms = now_ms() - t0;
+    g_build_single.store(0);
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t bytes) { const unsigned char *q = (const unsigned char *)p; for (size_t k = 0; k < bytes; ++k) { h ^= q[k]; h *= 1099511628211ull; } };
+    mix(nodes.data(), nodes.size() * sizeof(float));
+    mix(grid_cells.data(), grid_cells.size() * sizeof(int));
+    mix(&d.bvh_root, sizeof(int)); mix(&d.grid_tall, sizeof(int)); mix(&d.bvh_node16, sizeof(int));
+    *out_hash = h;
+    out_info[0] = (int32_t)(nodes.size() / (d.bvh_node16 ? 8 : 16)); out_info[1] = depth; out_info[2] = d.grid_n; out_info[3] = d.n_big;
+    return RTMI_OK;
+}
+RTMI_EXPORT int rtmi_test_half_outward(double x, int32_t up) { return (int)half_outward((float)x, up != 0); } // test hook (host arithmetic only: no device needed)
 RTMI_EXPORT const char *rtmi_last_error(void) { return g_err.c_str(); }
 RTMI_EXPORT const char *rtmi_backend_name(void) { return "hip-gfx950"; }
 RTMI_EXPORT int rtmi_version(void) { return 204; } // 204: rtmi_probe_math2 (explicit slot count; rtmi_probe_math writes 8 values per triple again)
@@ -1583,6 +1831,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
                                      int32_t cam_kind, const double *cam, const int32_t *prim_flip, const int32_t *prim_xform,
                                      int32_t n_xforms, const int32_t *xform_kind, const double *xform_param, rtmi_scene **out_scene) {
     if (!ctx_ok(c)) return fail(RTMI_E_STATE, "invalid context handle");
+    const double t_create0 = now_ms();
     if (n_xforms < 0 || (n_xforms > 0 && (!xform_kind || !xform_param || !prim_xform))) return fail(RTMI_E_ARG, "xform arrays are NULL");
     for (int k = 0; k < n_xforms; ++k)
         if (xform_kind[k] != RTMI_XFORM_TRANSLATE && xform_kind[k] != RTMI_XFORM_ROTATE_Y) return fail(RTMI_E_UNSUPPORTED, "xform %d: kind %d unsupported on GPU path", k, xform_kind[k]);
@@ -1827,11 +2076,23 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     for (int k = 0; k < n_media; ++k) d.media_idx[k] = media[k];
     s->host_kind = pk;
     std::vector<int> grid_cells;
-    const std::vector<float> bvh_nodes = build_bvh(d, n_world, pk.data(), wbox, bounded, cam, !has_ext, grid_cells, box_first, &s->bvh_depth);
+    const double t_create1 = now_ms();
+    std::vector<BvhBox> media_boxes; // per ConstantMedium: the box of its boundary (if every boundary primitive can be bounded)
+    for (int k = 0; k < n_media; ++k) {
+        const double *mg = prim_geom + (size_t)media[k] * RTMI_PRIM_STRIDE;
+        const int fb = (int)mg[1], nb = (int)mg[2];
+        BvhBox u = box_empty();
+        bool ok = true;
+        for (int q = fb; q < fb + nb; ++q) { ok = ok && bounded[(size_t)q]; if (ok) box_grow(u, wbox[(size_t)q]); }
+        if (ok) media_boxes.push_back(u);
+    }
+    const std::vector<float> bvh_nodes = build_bvh(d, n_world, pk.data(), wbox, bounded, cam, !has_ext, grid_cells, box_first, &s->bvh_depth, &media_boxes);
     s->bvh_node_count = (int)(bvh_nodes.size() / (d.bvh_node16 ? 8 : 16));
     if (std::getenv("RTMI_DEBUG"))
         fprintf(stderr, "[rtmi] tree: %d node records of %d bytes (%.2f MB), depth %d, %d big primitives, %d box leaves; entry grid %d x %d cells, %zu rectangle trees\n", s->bvh_node_count,
                 d.bvh_node16 ? 32 : 64, s->bvh_node_count * (d.bvh_node16 ? 32.0 : 64.0) / 1e6, s->bvh_depth, d.n_big, (int)std::count(box_first.begin(), box_first.end(), (char)1), d.grid_n, d.grid_n, grid_cells.size());
+    if (std::getenv("RTMI_DEBUG") && d.n_mloc) fprintf(stderr, "[rtmi] %d medium neighbourhood tree(s)\n", d.n_mloc);
+    const double t_create2 = now_ms();
     if (!rc) rc = upload(s, bvh_nodes, &d.bvh_nodes);
     if (!rc) rc = upload(s, grid_cells, &d.grid_cells);
     std::vector<int> moving_all;
@@ -1957,6 +2218,9 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
         s->d_dev = (ScenePtr)dp;
     }
     if (rc) { rtmi_scene_destroy(s); return rc; }
+    if (std::getenv("RTMI_DEBUG"))
+        fprintf(stderr, "[rtmi] scene create: records %.2f ms, trees %.2f ms, tables + upload (%zu allocations, %.2f MB) %.2f ms\n", t_create1 - t_create0, t_create2 - t_create1,
+                s->allocs.size(), (double)s->device_bytes / 1e6, now_ms() - t_create2);
     {
         rtmi_scene::Args &A = s->args;
         A.prim_kind.assign(prim_kind, prim_kind + n_prims); A.prim_mat.assign(prim_mat, prim_mat + n_prims);
@@ -2050,6 +2314,13 @@ RTMI_EXPORT int rtmi_scene_set_images(rtmi_scene *s, int32_t n_images, const int
     s->dev.n_images = n_images;
     s->args.image_wh = whv; s->args.image_rgb = px;
     return reupload_descriptor(s);
+}
+
+RTMI_EXPORT int rtmi_scene_device_bytes(rtmi_scene *s, int64_t *out_bytes) {
+    if (!scene_ok(s)) return fail(RTMI_E_STATE, "invalid scene handle");
+    if (!out_bytes) return fail(RTMI_E_ARG, "out_bytes is NULL");
+    *out_bytes = (int64_t)s->device_bytes;
+    return RTMI_OK;
 }
 
 RTMI_EXPORT int rtmi_scene_destroy(rtmi_scene *s) {

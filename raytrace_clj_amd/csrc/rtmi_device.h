@@ -59,6 +59,12 @@ struct DevScene {
     const double *leaf_rec;  // [n_all][14]: everything a tree leaf's exact test reads, in ONE 112-byte record (LeafRec: one round trip instead of info -> chain -> geometry)
     const int *ext_info;     // [n_all][4]: kind, FlipNormals parity, first xform, xform count (outermost first)
     const double *ext_xf;    // [n_xforms][4]: 0 | offset.xyz  (Translate)   or   1 | sin, cos, 0  (RotateY)
+    // Neighbourhood trees of the media (RTMI_MEDIA_DESCENT): a segment that a medium hit bounds INSIDE the box of that medium's boundary -- a path scattering in
+    // make-final's subsurface sphere: a third of that scene's segments, each a few units long -- can only meet the surfaces that reach into that box: its
+    // traversal starts at a tree over those (scan_bvh_ext) instead of locating itself from the root of the whole tree.
+    int n_mloc;              // number of such regions (media whose boundary box holds less than half of the tree's primitives)
+    int mloc_root[4];        // root code of the region's tree (RTMI_BVH_EMPTY: no surface reaches into it)
+    float mloc_box[4][6];    // lo.xyz hi.xyz: every surface point inside this box belongs to a primitive of the region's tree (the device shrinks it by the float error of a ray's end points)
     int media_seq;           // RTMI_MEDIA_HITLIST: the world is a Hitlist (hitable.clj:15-26), a medium's hit? sees the t-max narrowed by the items before it
     int n_media;             // hit? invocations of ConstantMedium primitives (hitable.clj:516) per ray, in the reference's call order
     int media_idx[32];       // (a medium may appear twice: rtmi_scene_set_media_calls); exact12 = density, first boundary prim, count
@@ -1741,6 +1747,17 @@ __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> 
         if (COUNT) cnt[1] += (unsigned)sc.n_big;
         for (int k = 0; k < sc.n_big; ++k) if (sc.big_idx[k] >= lo && sc.big_idx[k] < hi) ext_prim_test<true>(sc, sc.big_idx[k], P, tmin, H);
         cur = bvh_cursor_at_root(sc, stack);
+        if (sc.n_mloc > 0 && !sc.media_seq && lo == 0 && H.t < 1e30) { // (wave-uniform) a bounded segment: does it lie inside a medium's neighbourhood?
+            const float ox = (float)P.ox, oy = (float)P.oy, oz = (float)P.oz, tb = (float)H.t;
+            const float px = fmaf(tb, (float)P.dx, ox), py = fmaf(tb, (float)P.dy, oy), pz = fmaf(tb, (float)P.dz, oz); // where the bound cuts the ray
+            // both end points carry a float error below 2^-21 (|o| + |p|): the box is shrunk by 2^-16 of that, like the entry grid's rectangles are grown
+            const float e = (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + fmaxf(fmaxf(fabsf(px), fabsf(py)), fabsf(pz))) * (1.0f / 65536.0f);
+            for (int k = 0; k < sc.n_mloc; ++k) {
+                const float lx = sc.mloc_box[k][0] + e, ly = sc.mloc_box[k][1] + e, lz = sc.mloc_box[k][2] + e, hx = sc.mloc_box[k][3] - e, hy = sc.mloc_box[k][4] - e, hz = sc.mloc_box[k][5] - e;
+                const bool in = ox >= lx && ox <= hx && oy >= ly && oy <= hy && oz >= lz && oz <= hz && px >= lx && px <= hx && py >= ly && py <= hy && pz >= lz && pz <= hz; // (a NaN: false)
+                if (in) cur.node = sc.mloc_root[k]; // convex: the whole segment is inside
+            }
+        }
         RTMI_PH(PH_BIG)
     }
     auto leaf = [&](int code) { // one primitive, or the six faces of a Box (RTMI_LEAF_BOX: one chain, one local ray, three divisors)

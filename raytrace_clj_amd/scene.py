@@ -182,9 +182,10 @@ def make_subsurface_sphere(nx, ny, seed=SCENE_SEED):
     }
 
 
-def make_final(nx, ny, image=None, seed=SCENE_SEED):
+def make_final(nx, ny, image=None, seed=SCENE_SEED, parts=None):
     """book 2 final example -- scene.clj:415-489, the scene raytrace-clj.core/-main renders as shipped (core.clj:90).
-    earth.png is not in the reference repository: `image` (default synthetic_earth()) stands in."""
+    earth.png is not in the reference repository: `image` (default synthetic_earth()) stands in.
+    parts (experiments only, scripts/gpu_final_variants.py): the names of the world's items to keep (default: all eleven)."""
     rng = SplitMix64(seed)
     rand = rng.rand
     white = shad.lambertian(albedo=tex.constant(color=vec3(0.73, 0.73, 0.73)))
@@ -206,23 +207,24 @@ def make_final(nx, ny, image=None, seed=SCENE_SEED):
             boxes.append(hit.box(p0=p0, p1=p1, material=ground))
     ground_bvh = hit.make_bvh(boxes, 0.0, 1.0, rng)
     packed = hit.make_bvh([hit.sphere(center=165.0 * vec3(rand(), rand(), rand()), radius=10, material=white) for _ in range(ns)], 0.0, 1.0, rng)
+    items = [
+        ("ground", ground_bvh),
+        ("light", hit.rect_xz(x0=123, z0=147, x1=423, z1=412, k=554, material=light)),
+        ("moving", hit.moving_sphere(center0=vec3(400, 400, 200), t0=0, center1=vec3(430, 400, 200), t1=1, radius=50, material=orange)),
+        ("glass", hit.sphere(center=vec3(260, 150, 45), radius=50, material=glass)),
+        ("metal", hit.sphere(center=vec3(0, 150, 145), radius=50, material=metal)),
+        ("bndry", bndry),
+        ("medium", hit.constant_medium(boundary=bndry, density=0.2, albedo=tex.constant(color=vec3(0.2, 0.4, 0.9)))),
+        ("haze", hit.constant_medium(boundary=hit.sphere(center=vec3(0, 0, 0), radius=5000, material=glass), density=0.0001,
+                                     albedo=tex.constant(color=vec3(1, 1, 1)))),
+        ("earth", hit.uv_sphere(center=vec3(400, 200, 400), radius=100, material=earth)),
+        ("marble", hit.sphere(center=vec3(220, 280, 300), radius=80, material=marble)),
+        ("cube", hit.translate(item=hit.rotate_y(item=packed, theta=15), offset=vec3(-100, 270, 395))),
+    ]
     return {
         "camera": cam.thin_lens_camera(lookfrom=vec3(478, 278, -600), lookat=vec3(278, 278, 0), vup=vec3(0, 1, 0), vfov=40,
                                        aspect=_aspect(nx, ny), aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0),
-        "world": hit.make_bvh([
-            ground_bvh,
-            hit.rect_xz(x0=123, z0=147, x1=423, z1=412, k=554, material=light),
-            hit.moving_sphere(center0=vec3(400, 400, 200), t0=0, center1=vec3(430, 400, 200), t1=1, radius=50, material=orange),
-            hit.sphere(center=vec3(260, 150, 45), radius=50, material=glass),
-            hit.sphere(center=vec3(0, 150, 145), radius=50, material=metal),
-            bndry,
-            hit.constant_medium(boundary=bndry, density=0.2, albedo=tex.constant(color=vec3(0.2, 0.4, 0.9))),
-            hit.constant_medium(boundary=hit.sphere(center=vec3(0, 0, 0), radius=5000, material=glass), density=0.0001,
-                                albedo=tex.constant(color=vec3(1, 1, 1))),
-            hit.uv_sphere(center=vec3(400, 200, 400), radius=100, material=earth),
-            hit.sphere(center=vec3(220, 280, 300), radius=80, material=marble),
-            hit.translate(item=hit.rotate_y(item=packed, theta=15), offset=vec3(-100, 270, 395)),
-        ], 0.0, 1.0, rng),
+        "world": hit.make_bvh([it for name, it in items if parts is None or name in parts], 0.0, 1.0, rng),
     }
 
 

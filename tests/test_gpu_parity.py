@@ -614,10 +614,17 @@ def test_bench_json_schema():
     assert d["aabb_tests_per_segment"] > 2 and d["prim_tests_per_segment"] >= 2
     assert d["pipelined"]["value"] > 100 and d["c2"]["value"] > 100 and d["c4"]["value"] > 100 and d["c2"]["workload"].startswith("C2: 800x400x64spp")
     assert d["c5"]["value"] > 100 and d["c5"]["workload"].startswith("C5: 1920x1080x4096spp") and d["c5"]["segments_per_sample"] > 2.8  # the divergence-stress configuration
-    if rf["frac"] is not None:  # a PMC profile of this workload is committed: the calibrated issue model and the lane occupancy come with it
+    # section 8(d): scene upload reported separately and included in an end-to-end figure (what a one-frame host pays, core.clj:73-113)
+    assert 0 < d["scene_create_ms"] < d["end_to_end_ms"] and d["upload_bytes"] > 1_000_000 and d["end_to_end_ms"] >= d["scene_create_ms"] + rf["launch_ms"]
+    assert d["scene_create_ms"] <= 25, "scene creation at C3 (10 001 spheres, 11 025 rectangle trees) is multi-threaded: %s ms" % d["scene_create_ms"]
+    if rf["frac"] is not None:  # a PMC profile of this workload is committed: the hardware counter is the headline, the priced model a cross-check
         im = rf["issue_model"]
-        assert 0 < im["frac_low"] <= rf["frac"] <= im["frac_high"] <= 1 and set(im["per_class_price_cycles"]) >= {"FMA_F64", "INT32", "OTHER"}
+        assert "SQ_ACTIVE_INST_VALU" in rf["frac_source"] and 0 < rf["frac"] <= 1  # a counter cannot exceed the clock
+        assert 0 < im["frac_low"] <= im["frac"] <= im["frac_high"] and set(im["per_class_price_cycles"]) >= {"FMA_F64", "INT32", "OTHER"}  # the model is NOT clamped
+        assert im["over_counter"] == pytest.approx(im["frac"] / rf["frac"], rel=1e-3) and im["agrees_with_counter"] in (True, False)
         assert 0.3 < rf["lanes_active"] <= 1 and rf["counts"]["stale"] in (True, False)
+        assert rf["useful_lane_frac"] == pytest.approx(rf["frac"] * rf["lanes_active"], abs=1e-3) and 0 < rf["fp_frac"] < rf["useful_lane_frac"]
+        assert rf["fp"]["frac"] == rf["fp_frac"] and rf["fp"]["fp64_tflops"] < 78.6 and rf["fp"]["fp32_tflops"] < 157.3
         for k in ("c2", "c4", "c5"):
             assert d[k]["roofline"]["frac"] is None or 0 < d[k]["roofline"]["frac"] <= 1
 
@@ -639,6 +646,23 @@ def test_two_rank_control_flow_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["ns"] == 4 and d["value"] > 0 and "cpu_baseline" not in d and d["rehearsal"]
     assert abs(d["config"]["segments_per_sample"] - 2.5) < 0.6  # both ranks' segment counters were summed
     assert d["gather_ms"] >= 0
+    # the line proves what ran: rank count and backend from torch.distributed itself, every rank's device, kernel time, segments and tiles
+    rk = d["ranks"]
+    assert rk["n"] == 2 and rk["backend"] == "gloo" and "gloo" in d["gather_path"] and len(rk["per_rank"]) == 2
+    assert [e["rank"] for e in rk["per_rank"]] == [0, 1] and all(e["trace_ms"] > 0 and e["segments"] > 0 and e["tiles"] > 0 and e["device_name"] for e in rk["per_rank"])
+    assert abs(sum(e["segments"] for e in rk["per_rank"]) - d["config"]["segments_per_sample"] * 200 * 100 * 4) <= 8  # (segments_per_sample is rounded to 4 decimals)
+    assert sum(e["tiles"] for e in rk["per_rank"]) == 25 * 13 and rk["gather_bytes"] == ((25 * 13 + 1) // 2) * 64 * 3 * 8
+    assert rk["distinct_devices"] is False and rk["imbalance"] >= 1.0 and rk["trace_ms_max"] >= rk["trace_ms_min"] > 0  # (both ranks share this box's GPU: a rehearsal)
+    # ... and outside a rehearsal two ranks on one device are an error, not a valid-looking line
+    import subprocess
+    env2 = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env2.pop("RTMI_BENCH_REHEARSAL", None)
+    import torch
+    if torch.cuda.device_count() < 2:
+        env2["RTMI_BENCH_SHARE_DEVICE"] = "1"  # test hook: both ranks bind device 0 (a mis-launched job) while the line claims a measurement
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29543",
+                            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "C1"], env=env2, capture_output=True, text=True, timeout=600)
+        assert p.returncode != 0 and "two ranks report the same device" in p.stdout
 
 
 def test_bench_gpus_n_in_one_process():
@@ -650,6 +674,8 @@ def test_bench_gpus_n_in_one_process():
     assert d.get("rehearsal", False) == (torch.cuda.device_count() < 2)
     assert abs(d["config"]["segments_per_sample"] - 2.5) < 0.6 and d["gather_ms"] >= 0
     assert d["gather_path"] == ("same-device" if torch.cuda.device_count() < 2 else "rccl")  # on distinct devices bench.py forces RCCL: never silent peer copies
+    rp = d["replicas"]  # every replica's launches, not replica 0's
+    assert rp["n"] == 2 and len(rp["trace_ms_per_step"]) == 2 and all(x > 0 for x in rp["trace_ms_per_step"]) and rp["trace_ms_max"] >= rp["trace_ms_min"] > 0 and rp["imbalance"] >= 1.0
 
 
 def test_frame_pipeline_renders_the_same_frames():

@@ -337,3 +337,53 @@ def test_bench_roofline_object_is_consistent():
     assert none["frac"] is None and none["traffic"] is None and none["hbm"]["frac"] < 1
     flat = bench.roofline("C2", "flat", "f64", 488, 9.3e-3, 1, dict(counts, segments=5.24e7, samples=2.05e7, pixels=3.2e5))
     assert "flat_scan_flops" in flat and flat["on_chip_fetch"]["frac"] < 1
+
+
+def test_half_outward_is_directed_rounding_to_half():
+    """the tree's half-plane node records round every box plane OUTWARD to IEEE half (rtmi.hip: half_outward, integer arithmetic on the float's bits): against
+    numpy's round-to-nearest half stepped to the neighbour on the required side -- one million floats over the whole half range and beyond, subnormals, signed
+    zeros, ties, the overflow threshold, infinities.  Host arithmetic only."""
+    L = _ffi.lib()
+    rng = np.random.default_rng(3)
+    x = np.concatenate([
+        (rng.normal(0, 1, 400000) * 10.0 ** rng.integers(-9, 6, 400000)),
+        rng.uniform(-70000, 70000, 200000), rng.uniform(-1e-4, 1e-4, 200000), rng.uniform(-2.0 ** -14, 2.0 ** -14, 100000),
+        np.arange(-2048, 2049) * 2.0 ** -24, np.arange(-2048, 2049) * 2.0 ** -25, np.float32(65504.0) + np.arange(-64, 65) * np.float32(0.5),
+        [0.0, -0.0, 65504.0, 65519.99, 65520.0, 65535.9, 65536.0, 1e30, -1e30, np.inf, -np.inf, 5.9604645e-08, 2.98e-08, 1e-45, -1e-45, 6.1035156e-05, -6.1035156e-05],
+    ]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        h = x.astype(np.float16)  # round to nearest even
+        back = h.astype(np.float32)
+        up = np.where(back < x, np.nextafter(h, np.float16(np.inf)), h)
+        dn = np.where(back > x, np.nextafter(h, np.float16(-np.inf)), h)
+    # the signed zero the library returns when nothing is stepped is numpy's too (RN keeps the sign); a stepped zero has a sign by construction
+    got_up = np.array([L.rtmi_test_half_outward(float(v), 1) for v in x[:200000]], np.uint16)
+    got_dn = np.array([L.rtmi_test_half_outward(float(v), 0) for v in x[:200000]], np.uint16)
+    idx = np.concatenate([np.arange(200000), np.arange(len(x) - 9000, len(x))])
+    got_up = np.concatenate([got_up, [L.rtmi_test_half_outward(float(v), 1) for v in x[-9000:]]]).astype(np.uint16)
+    got_dn = np.concatenate([got_dn, [L.rtmi_test_half_outward(float(v), 0) for v in x[-9000:]]]).astype(np.uint16)
+    gu, gd = got_up.view(np.float16), got_dn.view(np.float16)
+    xs = x[idx]
+    assert np.all(gu.astype(np.float32) >= xs) and np.all(gd.astype(np.float32) <= xs)               # conservative
+    assert np.array_equal(gu, up[idx]) and np.array_equal(gd, dn[idx])                                    # ... and the closest such half
+    nz = xs != 0
+    assert np.array_equal(got_up[nz], up[idx][nz].view(np.uint16)) and np.array_equal(got_dn[nz], dn[idx][nz].view(np.uint16))  # bit for bit away from zero
+
+
+def test_tree_build_is_the_same_on_one_thread_and_on_the_team():
+    """rtmi_scene_create builds the device's tree and the entry grid's rectangle trees (C3: 11 025 of them) on a team of threads: every job builds in a builder
+    of its own and the results are appended in job order, so the node array and the grid's root codes do not depend on the thread count.  Host code only."""
+    L = _ffi.lib()
+    import raytrace_clj_amd as r
+    from raytrace_clj_amd import flatten as fl
+    for n, cells in ((11, 12), (24, 26)):
+        f = fl.flatten(r.scene.make_random_scene(800, 400, n, False))
+        geom = np.ascontiguousarray(f.prim_geom[:, :4])
+        cam = np.ascontiguousarray(f.cam)
+        out = []
+        for threads in (1, 8, 1, 8):
+            h, info, ms = np.zeros(1, np.uint64), np.zeros(4, np.int32), np.zeros(1)
+            assert L.rtmi_test_build_tree(len(geom), _ffi.ptr(geom), _ffi.ptr(cam), threads, _ffi.ptr(h), _ffi.ptr(info), _ffi.ptr(ms)) == 0
+            out.append((int(h[0]), tuple(int(v) for v in info)))
+        assert len(set(out)) == 1, out
+        assert out[0][1][2] == cells and out[0][1][3] == 2 and out[0][1][0] > 4 * cells * cells  # an entry grid of that many cells per side, dome + ground kept out of the tree
