@@ -1559,24 +1559,26 @@ std::vector<float> build_bvh(DevScene &d, int n_prims, const int *prim_kind, con
                 }
                 if (std::getenv("RTMI_DEBUG")) fprintf(stderr, "[rtmi] build: %zu rectangle trees on %u threads %.2f ms\n", n_jobs, build_threads(), now_ms() - tr0);
                 join_whole();
-                size_t total_nodes = B.nodes.size();
-                for (const RectTree &T : trees) total_nodes += T.nodes.size();
-                B.nodes.reserve(total_nodes + 1024);
-                for (size_t jb = 0; jb < n_jobs; ++jb) { // append in job order, node offsets rebased
-                    RectTree &T = trees[jb];
-                    B.max_depth = std::max(B.max_depth, T.depth);
-                    if (T.root == RTMI_BVH_EMPTY) continue;
-                    const int base = (int)(B.nodes.size() / 16) * 64;
-                    for (size_t nd = 0; nd < T.nodes.size() / 16; ++nd) {
-                        int c[2];
-                        std::memcpy(c, &T.nodes[nd * 16 + 12], 8);
-                        for (int k = 0; k < 2; ++k) if (c[k] >= 0) c[k] += base; // inner node: byte offset of its record (leaf codes and RTMI_BVH_EMPTY are negative)
-                        std::memcpy(&T.nodes[nd * 16 + 12], c, 8);
+                // append in job order, node offsets rebased: every job's place in the array is the sum of the sizes before it, so the copies run on the team too
+                std::vector<size_t> at(n_jobs + 1, B.nodes.size());
+                for (size_t jb = 0; jb < n_jobs; ++jb) { at[jb + 1] = at[jb] + trees[jb].nodes.size(); B.max_depth = std::max(B.max_depth, trees[jb].depth); }
+                B.nodes.resize(at[n_jobs]);
+                parallel_blocks(n_jobs, 64, [&](size_t b, size_t e) {
+                    for (size_t jb = b; jb < e; ++jb) {
+                        RectTree &T = trees[jb];
+                        if (T.root == RTMI_BVH_EMPTY) continue;
+                        const int base = (int)(at[jb] / 16) * 64;
+                        float *dst = &B.nodes[at[jb]];
+                        std::memcpy(dst, T.nodes.data(), T.nodes.size() * sizeof(float));
+                        for (size_t nd = 0; nd < T.nodes.size() / 16; ++nd) {
+                            int c[2];
+                            std::memcpy(c, dst + nd * 16 + 12, 8);
+                            for (int k = 0; k < 2; ++k) if (c[k] >= 0) c[k] += base; // inner node: byte offset of its record (leaf codes and RTMI_BVH_EMPTY are negative)
+                            std::memcpy(dst + nd * 16 + 12, c, 8);
+                        }
+                        grid_cells[jb] = T.root + base;
                     }
-                    B.nodes.insert(B.nodes.end(), T.nodes.begin(), T.nodes.end());
-                    grid_cells[jb] = T.root + base;
-                    std::vector<float>().swap(T.nodes);
-                }
+                });
             }
             join_whole();
             if (d.bvh_root < 0) cell_items.clear(); // (the whole tree did not fit the stack: every ray takes the flat scan, no grid either)
@@ -2145,9 +2147,12 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
                 if (k == RTMI_TEX_UVGRADIENT) { // co cu cv cuv: a = cu (1-u) + co u, b = cuv (1-u) + cv u, out = b (1-v) + a v  (texture.clj:26-34)
                     const double *tp = tex_param + (size_t)t * RTMI_TEX_STRIDE;
                     bool var_u = false, var_v = false;
+                    // "does not vary" is a comparison of BITS (memcmp), not of values: only then is the lerp of the two colours at u = 1/2 the colour itself
+                    // whatever it holds (c/2 + c/2 = c exactly; +0 against -0, or two different NaNs, count as varying and keep the real coordinate)
+                    auto same = [&](int a, int b) { return std::memcmp(&tp[a], &tp[b], sizeof(double)) == 0; };
                     for (int c = 0; c < 3; ++c) {
-                        var_u = var_u || !(tp[c] == tp[3 + c]) || !(tp[6 + c] == tp[9 + c]);     // co != cu or cv != cuv (NaN: keep)
-                        var_v = var_v || !(tp[c] == tp[6 + c]) || !(tp[3 + c] == tp[9 + c]);     // co != cv or cu != cuv
+                        var_u = var_u || !same(c, 3 + c) || !same(6 + c, 9 + c);     // co != cu or cv != cuv
+                        var_v = var_v || !same(c, 6 + c) || !same(3 + c, 9 + c);     // co != cv or cu != cuv
                     }
                     u = (char)((var_u ? 1 : 0) | (var_v ? 2 : 0));
                 }

@@ -348,3 +348,69 @@ def test_gpu_clj_reads_only_fields_the_reference_records_have():
     imports = [f for f in walk(forms[0]) if is_list(f, ":import")]
     imported = {x for f in imports for grp in f[2:] if isinstance(grp, list) for x in grp[2:] if isinstance(x, str)}
     assert set(REFERENCE_RECORDS) <= imported, set(REFERENCE_RECORDS) - imported
+
+
+# ---- clj/test/raytrace_clj/gpu_test.clj: the test a maintainer runs first (never run here: no JVM) -- read statically ----------------------------------
+# the reference's scene functions and their parameter lists (scene.clj:9, 230, 318), as data
+REFERENCE_SCENE_FNS = {"make-two-spheres": 2, "make-cornell-box": 2, "make-random-scene": 4}
+GPU_TEST_CLJ = os.path.join(ROOT, "clj", "test", "raytrace_clj", "gpu_test.clj")
+CLJ_FIXTURES = os.path.join(ROOT, "clj", "test", "resources")
+
+
+def _edn_keys(text):
+    """top-level keywords of the fixture map (the files are written by scripts/export_clj_fixtures.py: one `:key value` per line)"""
+    import re
+    assert text.count("{") == text.count("}") == 1 and text.count("[") == text.count("]")
+    return set(re.findall(r"(?m)^[ {]:([a-z0-9-]+) ", text)) | set(re.findall(r" :(ny|nx) ", text))
+
+
+def test_gpu_test_clj_refers_to_things_that_exist():
+    """the Clojure test calls the reference's scene functions with the arity scene.clj declares, gpu.clj vars that gpu.clj defines, reads fixture keys the
+    exported fixtures hold, and every fixture is the scene of the golden .npz it was exported from (the exporter asserts that when it runs)"""
+    forms = read_forms(open(GPU_TEST_CLJ).read())
+    ns = forms[0]
+    assert is_list(ns, "ns") and ns[2] == "raytrace-clj.gpu-test"
+    requires = {v[1]: v[3] for req in walk(ns) if is_list(req, ":require") for v in req[2:] if isinstance(v, list) and v[0] == "[" and len(v) >= 4 and v[2] == ":as"}
+    assert requires.get("raytrace-clj.scene") == "scene" and requires.get("raytrace-clj.gpu") == "gpu" and requires.get("clojure.edn") == "edn"
+    gpu_defs = {f[2] for f in read_forms(open(GPU_CLJ).read()) if is_list(f) and f[1] in ("defn", "def") and isinstance(f[2], str)}
+    calls = {"scene": [], "gpu": []}
+    for top in forms:
+        for f in walk(top):
+            if is_list(f) and isinstance(f[1], str) and "/" in f[1]:
+                alias, name = f[1].split("/", 1)
+                if alias in calls:
+                    calls[alias].append((name, len(f) - 2))
+    assert {n for n, _ in calls["scene"]} == set(REFERENCE_SCENE_FNS)
+    for name, argc in calls["scene"]:
+        assert argc == REFERENCE_SCENE_FNS[name], "(scene/%s ...) with %d arguments, scene.clj declares %d" % (name, argc, REFERENCE_SCENE_FNS[name])
+    assert {n for n, _ in calls["gpu"]} <= gpu_defs and {"flatten-scene", "render"} <= {n for n, _ in calls["gpu"]}
+    # fixtures: present, balanced, and holding every key the test reads off them
+    read_keys = {f[1][1:] for top in forms for f in walk(top) if is_list(f) and len(f) == 3 and isinstance(f[1], str) and f[1].startswith(":") and f[2] in ("fx", ["~", "fx"])}
+    names = {f[2].strip('"') for top in forms for f in walk(top) if is_list(f, "fixture") and len(f) == 3 and isinstance(f[2], str) and f[2].startswith('"')}
+    assert names == {"two_spheres", "cornell_box", "cover_n3"} and read_keys >= {"scene-seed", "bvh-axes", "nx", "ny", "cam", "prim-kind"}
+    for n in names:
+        keys = _edn_keys(open(os.path.join(CLJ_FIXTURES, n + ".edn")).read())
+        assert read_keys <= keys | {"prim-flip", "prim-xform", "xform-kind", "xform-param"}, (n, read_keys - keys)
+        assert {"scene-seed", "bvh-axes", "prim-kind", "prim-geom", "cam", "cam-kind"} <= keys
+    # ... and the keys it compares are keys flatten-scene's result map has
+    flat = [f for f in read_forms(open(GPU_CLJ).read()) if is_list(f, "defn") and f[2] == "flatten-scene"][0]
+    flat_keys = {m[k][1:] for m in walk(flat) if isinstance(m, list) and m[0] == "{" for k in range(1, len(m), 2) if isinstance(m[k], str) and m[k].startswith(":")}
+    compared = {f[2][1:] for top in forms for f in walk(top) if is_list(f, "get") and len(f) == 4 and f[2] == "f" or False for _ in [0]} if False else set()
+    for top in forms:
+        for f in walk(top):
+            if isinstance(f, list) and f[0] == "[" and len(f) == 3 and all(isinstance(x, str) and x.startswith(":") for x in f[1:]):
+                compared.add(f[1][1:])
+            if is_list(f) and len(f) == 3 and isinstance(f[1], str) and f[1].startswith(":") and f[2] in ("f", "f1", "f2", "out"):
+                compared.add(f[1][1:])
+    assert compared - {"rgb8", "total-pixels", "total-rays"} <= flat_keys, compared - flat_keys
+    assert {"prim-kind", "prim-geom", "cam", "cam-kind", "n-prims", "xform-param"} <= compared
+
+
+def test_clj_fixtures_are_the_golden_scenes():
+    """clj/test/resources/*.edn are re-exported from tests/golden/*.npz by the committed script and must not drift from them"""
+    import subprocess
+    import sys
+    before = {n: open(os.path.join(CLJ_FIXTURES, n)).read() for n in sorted(os.listdir(CLJ_FIXTURES))}
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "export_clj_fixtures.py")], stdout=subprocess.DEVNULL)
+    after = {n: open(os.path.join(CLJ_FIXTURES, n)).read() for n in sorted(os.listdir(CLJ_FIXTURES))}
+    assert before == after

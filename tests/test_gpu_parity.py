@@ -931,7 +931,12 @@ def test_media_match_oracle(oracle):
             # total-rays: a free-flight distance that lands within an ulp of the chord (ocml log vs glibc log) sends ONE path of the frame a
             # different way -- up to depth 50 segments of it (round 3's stream: one sample of make-final at pixel (8, 35), 131 vs 115 segments,
             # both black; BVH and flat scan agree with each other bit for bit there).  One path's worth of slack, no more.
-            assert abs(int(cnt[0]) - int(exp_cnt[0])) <= 52 + 1e-5 * int(exp_cnt[0]) and rms(lin, exp_lin) <= RMS_TOL, (name, accel, rms(lin, exp_lin))
+            # The bound is TIGHT (two segments) unless the frames show that flip: then at most ONE pixel of the frame may differ from the oracle's beyond the
+            # log's last bits (a path that took another way can only change its own pixel; a draw-order bug would change many) and the slack is that one path's.
+            seg_diff = abs(int(cnt[0]) - int(exp_cnt[0]))
+            moved = int((np.abs(lin - exp_lin).max(axis=2) > 1e-9).sum())
+            assert seg_diff <= 2 or (seg_diff <= 52 and moved <= 1), (name, accel, seg_diff, moved)
+            assert rms(lin, exp_lin) <= RMS_TOL, (name, accel, rms(lin, exp_lin))
         ds.close(); ctx.close()
         if name == "final":
             media = np.flatnonzero((f.prim_kind[:f.n_prims] & 15) == 7)

@@ -152,3 +152,28 @@ def test_box_runs_as_one_leaf_are_bit_identical(monkeypatch):
             lin, q, cnt = _frame(flat, 1, nx, ns)
             out.append((hits, lin, cnt))
         assert np.array_equal(out[0][0], out[1][0], equal_nan=True) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_unread_uv_coordinate_moves_a_sky_colour_by_one_ulp_at_most(oracle, cover11):
+    """The one deliberate device-vs-oracle deviation: a UVGradient whose corner colours do not vary along u (the cover scene's
+    sky, scene.clj:340-344: co = cu, cv = cuv, compared bit for bit at scene creation) is evaluated with u = 1/2 on the device -- no atan2 --, with the
+    reference's own u in the oracle: c (1 - u) + c u against c.  Pinned here: on 20 000 rays that end on the dome the two colours differ by at most ONE ulp per
+    channel, and nothing else differs -- same primitive, same t, p, normal bit for bit, same segment count (the dome scatters nothing: no draws)."""
+    flat = fl.flatten(cover11)
+    rng = np.random.default_rng(12)
+    n = 20000
+    d = rng.normal(0, 1, (n, 3))
+    d[:, 1] = np.abs(d[:, 1]) + 0.05                       # upwards: the sky
+    o = np.tile([0.0, 30.0, 0.0], (n, 1)) + rng.uniform(-5, 5, (n, 3))  # above every sphere
+    rays = np.concatenate([o, d, rng.uniform(0, 1, (n, 1))], axis=1)
+    keys = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+    ergb, enseg, elog, enlog = oracle.probe_paths(flat, rays, keys, depth=50, ctr0=0, max_seg=2)
+    ds = core.DeviceScene(flat)
+    rgb, nseg, log, nlog = ds.probe_paths(rays, keys, depth=50, ctr0=0, max_seg=2)
+    ds.close()
+    dome = int(np.flatnonzero((flat.prim_kind == fl.PRIM_UVSPHERE) & (flat.prim_geom[:, 3] == 1000.0))[0])  # (the flattener lists the world in bvh-node order)
+    assert np.all(enseg == 1) and np.array_equal(nseg, enseg) and np.all(elog[:, 0, 0] == dome)   # one segment, ending on the dome
+    assert np.array_equal(log, elog)                                                         # index, t, p, normal: bit for bit
+    ulp = np.spacing(np.abs(ergb))
+    assert np.all(np.abs(rgb - ergb) <= ulp) and np.abs(ergb).min() > 0.4
+    assert (rgb != ergb).mean() < 0.5   # (most colours are equal outright)
