@@ -264,6 +264,7 @@ def main():
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: C3 at --gpus 1, C4 at --gpus N > 1")
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the one-frame-host figure (scene_create_ms / upload_bytes / end_to_end_ms); profiling runs use it so that every trace_kernel dispatch is a timed-workload launch")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the pipelined / C2 / C4 / other-accel extra measurements")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--accel", default="bvh", choices=["flat", "bvh"], help="bvh = bvh-node descent (hitable.clj:97-123, what every reference scene builds); flat = Hitlist scan (hitable.clj:15-26)")
@@ -556,7 +557,7 @@ def main():
             o = measure(drv, other_accel, max(2, min(args.steps, 5)), 1, cfg, nx, ny, ns, n_prims)
             out["other_accel"] = {"accel": other_accel, "value": o["value"], "ms_per_step": o["ms_per_step"], "roofline": o["roofline"]}
     if rank == 0:
-        if world == 1:  # section 8(d): scene upload reported separately and included in an end-to-end figure
+        if world == 1 and not args.no_e2e:  # section 8(d): scene upload reported separately and included in an end-to-end figure
             drv_close = getattr(getattr(drv, "pl", None), "close", None)
             if drv_close:
                 drv_close()  # release the timed driver's workspace first: the one-frame host allocates its own

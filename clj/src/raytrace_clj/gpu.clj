@@ -50,6 +50,7 @@
 
 (defn- v3 [v] [(mat/mget v 0) (mat/mget v 1) (mat/mget v 2)])
 
+(def ^:private listings (atom 0))         ; counts the media listings of a Hitlist world during flatten-scene's walk
 (def ^:private media-modes (atom #{}))   ; how flatten-scene's walk reached the media: :descent (bvh-nodes only above) / :hitlist (Hitlists only above)
 
 (defprotocol GpuLeaves
@@ -77,7 +78,11 @@
                      (throw (ex-info "a ConstantMedium inside a Hitlist below a bvh-node is not supported on the GPU path"
                                      {:unsupported-on-gpu-path ConstantMedium})))
                    (swap! media-modes conj (if l :hitlist :descent))
-                   (leaf this c f))
+                   ;; a Hitlist world: WHERE a medium stands in the list decides the t-max it is handed (hitable.clj:15-26), so every LISTING of
+                   ;; the record is a primitive of its own (:listing n keeps dedup-leaves from folding a second listing into the first)
+                   (if l
+                     [{:leaf this :chain c :flip f :listing (swap! listings inc)}]
+                     (leaf this c f)))
   Sphere       (leaves [this c f l b] (leaf this c f))
   UVSphere     (leaves [this c f l b] (leaf this c f))
   MovingSphere (leaves [this c f l b] (leaf this c f))
@@ -102,7 +107,7 @@
   same instance chain (the same record under two different instances is two primitives)"
   [lid xs]
   (let [seen (java.util.HashSet.)]
-    (filterv #(.add seen [(lid (:leaf %)) (:chain %) (:flip %)]) xs)))
+    (filterv #(.add seen [(lid (:leaf %)) (:chain %) (:flip %) (:listing %)]) xs)))
 
 (defn- intern! [table obj build]
   ;; table: atom {:ids IdentityHashMap, :rows []}; children are interned first
@@ -170,6 +175,7 @@
   "{:camera c :world w} -> the flat arrays of include/rtmi.h (as Clojure primitive arrays)"
   [{:keys [camera world]}]
   (reset! images [])
+  (reset! listings 0)
   (reset! media-modes #{})
   (let [called    (vec (leaves world [] 0 false false))    ; hit? invocation order, repeats included
         _         (when (> (count @media-modes) 1)
@@ -177,7 +183,7 @@
                                     {:unsupported-on-gpu-path ConstantMedium})))
         lid       (leaf-id-fn)
         world-es  (dedup-leaves lid called)
-        key-of    (fn [e] [(lid (:leaf e)) (:chain e) (:flip e)])
+        key-of    (fn [e] [(lid (:leaf e)) (:chain e) (:flip e) (:listing e)])
         index-of  (zipmap (map key-of world-es) (range))
         media-calls (mapv #(index-of (key-of %)) (filter #(instance? ConstantMedium (:leaf %)) called))
         ;; every medium's boundary is flattened on its own and appended AFTER the world (kind | 16)

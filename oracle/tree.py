@@ -16,7 +16,12 @@ from raytrace_clj_amd import hitable as H
 def attach_tree(flat, world):
     leaves = []
     fl._leaves(world, leaves, set())  # world primitives only (media included, their boundaries not)
-    prim_index = {(id(o), chain, flip): i for i, (o, chain, flip) in enumerate(leaves)}
+    prim_index, medium_listings, listing_seen = {}, {}, {}
+    for i, (o, chain, flip) in enumerate(leaves):
+        key = (id(o), chain, flip)
+        if isinstance(o, H.ConstantMedium):  # a Hitlist world lists a medium as often as it stands in the list: the k-th visit of the walk below is its k-th primitive
+            medium_listings.setdefault(key, []).append(i)
+        prim_index.setdefault(key, i)
     mat_of_prim = flat.prim_mat
     kind, a, d, prim, children = [], [], [], [], []
 
@@ -70,7 +75,10 @@ def attach_tree(flat, world):
             a[n] = [walk(o.obj, chain + ((fl.XFORM_ROTATE_Y, (float(o.sin_theta), float(o.cos_theta), 0.0)),), flip), 0, 0]
             return n
         if isinstance(o, H.ConstantMedium):
-            i = prim_index[(id(o), chain, flip)]
+            key = (id(o), chain, flip)
+            k = listing_seen.get(key, 0)
+            listing_seen[key] = k + 1
+            i = medium_listings[key][min(k, len(medium_listings[key]) - 1)]  # (bvh-node worlds de-duplicate: one primitive however often the descent reaches it)
             n = new(N_MEDIUM, dd=[o.density], p=i)
             a[n] = [walk(o.boundary, chain, flip, boundary=True), 0, int(mat_of_prim[i])]
             return n

@@ -257,7 +257,9 @@ template <typename R> __device__ inline void start_sample(SceneRef sc, const Tra
 
 // SLICE: time-sliced BVH traversal (section 5.1b of DESIGN.md); the plain instantiation is kept for scenes whose tree is too small to gain
 template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICE = true, bool MSEQ = false>
-__global__ void __launch_bounds__(kTraceBlock, EXT ? RTMI_EXT_MIN_WAVES : RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
+// (the Hitlist-with-media (MSEQ) and the counting (COUNT) instantiations of the mixed-kind kernels need more than the 128 VGPRs of four waves per SIMD: rather
+// than spill, they are compiled for three -- rare worlds and a diagnostic; the kernels the benchmarks run keep four)
+__global__ void __launch_bounds__(kTraceBlock, EXT ? ((MSEQ || COUNT) ? 3 : RTMI_EXT_MIN_WAVES) : RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
     SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Prim4<R> *lds = reinterpret_cast<Prim4<R> *>(smem);

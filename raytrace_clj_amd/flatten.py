@@ -86,6 +86,16 @@ def _leaves(world, out, seen, chain=(), flip=0, in_list=False, calls=None, under
         if modes is not None:
             modes.add("hitlist" if in_list else "descent")
         key = (id(world), chain, flip)
+        if in_list:
+            # a Hitlist world: WHERE a medium stands in the list decides the t-max it is handed (hitable.clj:15-26), so every LISTING of the record is a
+            # primitive of its own at its own place (the same record listed twice draws twice, each time narrowed by the items before that listing)
+            occ = sum(1 for k in seen if k[:3] == key and len(k) == 4)
+            key = key + (occ,)
+            seen.add(key)
+            out.append((world, chain, flip))
+            if calls is not None:
+                calls.append(key)
+            return
         if calls is not None:
             calls.append(key)
         if key not in seen:
@@ -138,8 +148,6 @@ def flatten(scene_or_world, camera=None, perlin_seed=None):
     _leaves(world, leaves, set(), calls=medium_calls, modes=modes)
     if len(modes) > 1:
         raise UnsupportedOnGpuPath("the world reaches some ConstantMedium records through a Hitlist and others through bvh-nodes only: not supported on the GPU path")
-    if modes == {"hitlist"} and len(set(medium_calls)) != len(medium_calls):
-        raise UnsupportedOnGpuPath("the same ConstantMedium record listed twice in a Hitlist is not supported on the GPU path")
 
     textures, materials = _Interner(), _Interner()
     uses, images = {"perlin": False}, []
@@ -202,7 +210,14 @@ def flatten(scene_or_world, camera=None, perlin_seed=None):
             leaves.extend(b)
     fs = FlatScene()
     fs.n_world = n_world
-    index_of = {(id(o), chain, flip): i for i, (o, chain, flip) in enumerate(leaves[:n_world])}
+    index_of, listings = {}, {}
+    for i, (o, chain, flip) in enumerate(leaves[:n_world]):
+        key = (id(o), chain, flip)
+        if isinstance(o, hit.ConstantMedium) and modes == {"hitlist"}:  # the k-th listing of this record (see _leaves)
+            k = listings.get(key, 0)
+            listings[key] = k + 1
+            key = key + (k,)
+        index_of[key] = i
     fs.media_calls = np.array([index_of[k] for k in medium_calls], np.int32)
     fs.media_mode = 1 if modes == {"hitlist"} else 0  # RTMI_MEDIA_HITLIST: the list's t-max narrowing reaches the media (rtmi_scene_set_media_mode)
     n = len(leaves)

@@ -8,7 +8,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $line -d $OUT/pmc$i -o pmc$i --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > /dev/null 2> $OUT/pmc$i.err
+  timeout -k 10 240 rocprofv3 --pmc $line -d $OUT/pmc$i -o pmc$i --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-e2e "$@" > /dev/null 2> $OUT/pmc$i.err
   echo "pmc$i exit $? ($line)"
 done < $R/$PASSES
 cd $R

@@ -5,13 +5,13 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 (cd $R && python3 -c "import bench; print(bench.kernel_sha())" > $OUT/kernel_sha.txt)  # the sources this profile is taken with
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras "$@" > $OUT/bench_trace.json 2> $OUT/trace.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-e2e "$@" > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace exit $?"
 i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $line -d $OUT/pmc$i -o pmc$i --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > /dev/null 2> $OUT/pmc$i.err
+  timeout -k 10 200 rocprofv3 --pmc $line -d $OUT/pmc$i -o pmc$i --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-e2e "$@" > /dev/null 2> $OUT/pmc$i.err
   echo "pmc$i exit $? ($line)"
 done <<'PASSES'
 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES

@@ -385,7 +385,7 @@ def test_entry_grid_is_bit_identical_to_the_flat_scan(monkeypatch):
 
 
 # ---- ConstantMedium inside a Hitlist (hitable.clj:15-26 + 516-541) -------------------------------------------------------------------------------------
-def hitlist_media_scene(seed=5):
+def hitlist_media_scene(seed=5, fog_twice=False):
     """a world that IS a Hitlist (no make-bvh): surfaces, a fog ball in the middle of the list, more surfaces -- some of them inside and behind
     the fog --, a second medium bounded by a Box, nested Hitlists and a translated, rotated box"""
     from raytrace_clj_amd.util import vec3
@@ -405,6 +405,9 @@ def hitlist_media_scene(seed=5):
     smoke = H.constant_medium(boundary=H.box(p0=vec3(-4, 0, 1), p1=vec3(-1, 2, 4), material=grey), density=0.8, albedo=T.constant(color=vec3(0.1, 0.1, 0.1)))
     items.append(smoke)
     items += [ball() for _ in range(8)]
+    if fog_twice:
+        items.append(fog)                                                     # the SAME record listed again: asked a second time, narrowed by everything above
+        items += [ball() for _ in range(3)]
     cam = r.camera.thin_lens_camera(lookfrom=vec3(9, 3, 7), lookat=vec3(0, 1, 0), vup=vec3(0, 1, 0), vfov=40, aspect=2.0, aperture=0.0, focus_dist=10.0, t0=0.0, t1=1.0)
     return {"camera": cam, "world": H.hitlist(items=items)}
 

@@ -179,3 +179,45 @@ def test_unread_uv_coordinate_moves_a_sky_colour_by_a_few_ulps_at_most(oracle, c
     ulps = np.abs(rgb - ergb) / np.spacing(np.abs(ergb))
     assert ulps.max() <= 4.0 and np.abs(ergb).min() > 0.4, ulps.max()
     assert (rgb != ergb).mean() < 0.5 and ulps.mean() < 0.5
+
+
+def test_a_medium_listed_twice_in_a_hitlist_matches_the_nested_oracle(oracle):
+    """Hitlist.hit? asks every item in turn with the closest hit so far as t-max (hitable.clj:15-26): a ConstantMedium record that stands in the list TWICE is
+    asked twice -- two draws, the second narrowed by everything before the second listing (round 3 rejected such worlds).  The flatteners now make every listing
+    a primitive of its own at its own place (same boundary, same phase function); the device's RTMI_MEDIA_HITLIST scan then needs nothing new.  Checked against
+    the oracle's nested evaluation: segment logs, frames, BVH = flat scan; and the second listing must matter (the frame differs from the once-listed world's)."""
+    from oracle.tree import flatten_with_tree
+    from tests.test_gpu_round3 import hitlist_media_scene, rms, RMS_TOL
+    sc = hitlist_media_scene(fog_twice=True)
+    f = flatten_with_tree(sc)
+    assert f.media_mode == 1 and len(f.media_calls) == 3 and list(f.media_calls) == sorted(set(int(m) for m in f.media_calls))
+    a, b = int(f.media_calls[0]), int(f.media_calls[2])
+    assert np.array_equal(f.prim_geom[a][:1], f.prim_geom[b][:1]) and f.prim_mat[a] == f.prim_mat[b]  # the same density and phase function, two places
+    nx, ny, ns = 64, 32, 8
+    exp_lin, exp_q, exp_cnt = oracle.render(f, nx, ny, ns, 50, 0x5EED0002, nthreads=16)
+    rng = np.random.default_rng(2)
+    n = 4096
+    keys = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+    cam = oracle.probe_camera(f, rng.random((n, 2)), keys)
+    ctr0 = int(cam[:, 7].max())
+    ergb, enseg, elog, enlog = oracle.probe_paths(f, cam[:, :7], keys, depth=50, ctr0=ctr0, max_seg=6)
+    logged = np.arange(6)[None, :] < enlog[:, None]
+    assert (elog[:, :, 0][logged].astype(int) == b).sum() > 5, "paths must scatter at the SECOND listing too"
+    ctx = core.Context(0)
+    ds = core.DeviceScene(f, ctx=ctx)
+    frames = {}
+    for accel in (1, 0):
+        ctx.set_option("accel", accel)
+        rgb, nseg, log, nlog = ds.probe_paths(cam[:, :7], keys, depth=50, ctr0=ctr0, max_seg=6)
+        same = nseg == enseg
+        assert same.mean() > 0.995, accel
+        assert np.array_equal(log[same][:, :, 0], elog[same][:, :, 0]) and np.allclose(log[same], elog[same], rtol=1e-9, atol=1e-9), accel
+        lin, q, cnt = ds.render(nx, ny, ns)
+        assert abs(int(cnt[0]) - int(exp_cnt[0])) <= 52 and rms(lin, exp_lin) <= RMS_TOL, (accel, rms(lin, exp_lin), cnt, exp_cnt)
+        frames[accel] = (lin, cnt)
+    assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][1], frames[1][1])
+    ds.close()
+    once = core.DeviceScene(flatten_with_tree(hitlist_media_scene(fog_twice=False)), ctx=ctx)
+    lin1, q1, cnt1 = once.render(nx, ny, ns)
+    once.close(); ctx.close()
+    assert int(cnt1[0]) != int(frames[1][1][0])

@@ -131,8 +131,10 @@ def test_flatten_media_modes():
     assert f.media_mode == 0 and len(f.media_calls) >= 1
     with pytest.raises(flatten.UnsupportedOnGpuPath):
         flatten.flatten({"camera": cam, "world": H.bvh_node(a, H.hitlist(items=[b, fog]), a.bbox(0.0, 1.0))})  # (the reference's Hitlist has no bbox: built by hand)
-    with pytest.raises(flatten.UnsupportedOnGpuPath):
-        flatten.flatten({"camera": cam, "world": H.hitlist(items=[a, fog, b, fog])})
+    # the same record listed twice in a Hitlist (rejected until round 3): every listing is a primitive of its own, at its own place
+    f = flatten.flatten({"camera": cam, "world": H.hitlist(items=[a, fog, b, fog])})
+    assert f.media_mode == 1 and list(f.media_calls) == [1, 3] and f.n_prims == 4 and list(f.prim_kind[:4] & 15) == [0, 7, 0, 7]
+    assert list(f.prim_geom[1][:1]) == list(f.prim_geom[3][:1]) and f.prim_geom[1][1] != f.prim_geom[3][1]  # same density, each listing its own copy of the boundary
 
 
 def test_golden_rng():
