@@ -203,7 +203,7 @@ __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per
         if (active) {
             if (SLICED) {
                 const bool done = scan_bvh<R, COUNT, true>(sc, stack, P, a, tmin, best_t, best_i, [&]() { scan_cull_dispatch(sc, P, a, tmin, best_t, best_i); }, cnt,
-                                                           stack + RTMI_BVH_STACK * RTMI_BVH_STRIDE, *mid, min_lanes);
+                                                           stack + susp_off, *mid, min_lanes);
                 *mid = !done;
             } else scan_bvh<R, COUNT, false, !NOGRID>(sc, stack, P, a, tmin, best_t, best_i, [&]() { scan_cull_dispatch(sc, P, a, tmin, best_t, best_i); }, cnt);
         }
@@ -256,7 +256,8 @@ template <typename R> __device__ inline void start_sample(SceneRef sc, const Tra
 }
 
 // SLICE: time-sliced BVH traversal (section 5.1b of DESIGN.md); the plain instantiation is kept for scenes whose tree is too small to gain
-template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICE = true, bool MSEQ = false>
+// LST: the sphere (non-EXT) time-sliced BVH kernel with the camera-ray stash in LDS and stack columns sized by the scene's tree (launch site: when it fits)
+template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICE = true, bool MSEQ = false, bool LST = false>
 // (the Hitlist-with-media (MSEQ) and the counting (COUNT) instantiations of the mixed-kind kernels need more than the 128 VGPRs of four waves per SIMD: rather
 // than spill, they are compiled for three -- rare worlds and a diagnostic; the kernels the benchmarks run keep four)
 __global__ void __launch_bounds__(kTraceBlock, EXT ? ((MSEQ || COUNT) ? 3 : RTMI_EXT_MIN_WAVES) : RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(kTraceBlock, EXT ? ((MSEQ || COUNT) ? 3 : RTMI
     bool alive = false;
     bool exhausted = (total_items == 0);
     unsigned out_item = 0; // work item of the lane's path: its colour goes to samples[out_item]
-    constexpr bool LSTASH = EXT && RTMI_STASH && RTMI_EXT_LDS_STASH && !RTMI_EXT_NO_STASH;
+    constexpr bool LSTASH = (EXT && RTMI_STASH && RTMI_EXT_LDS_STASH && !RTMI_EXT_NO_STASH) || LST;
     constexpr bool STASH = RTMI_STASH && !(EXT && RTMI_EXT_NO_STASH) && !LSTASH;
     // LSTASH: entry e of wave w = words lst[k * kTraceBlock + e], k = 0..5 direction, 6..7 time, 8..9 stream state, 10 work item (-1: none), 11..16 origin
     // (only written / read when the camera's rays do not all start at one point).  Written and read by the same wave only.
@@ -464,7 +465,7 @@ __global__ void __launch_bounds__(kTraceBlock, EXT ? ((MSEQ || COUNT) ? 3 : RTMI
         // segments of the others.  Once the queue is empty nothing is gained by handing back early (suspend_lanes 0).
         R best_t; int best_i;
         intersect_world<R, MULTI, VARIANT, EXT, COUNT, SLICED, MSEQ, !SLICED>(sc, lds, tp.prims_per_tile, tp.n_ptiles, P, alive, tmin, tmax, best_t, best_i, ntrav,
-                                                                     &mid, exhausted ? 0 : tp.suspend_lanes, EXT ? tp.susp_off : RTMI_BVH_STACK * RTMI_BVH_STRIDE);
+                                                                     &mid, exhausted ? 0 : tp.suspend_lanes, (EXT || LST) ? tp.susp_off : RTMI_BVH_STACK * RTMI_BVH_STRIDE);
         RTMI_PH(PH_BVH_POST) // intersection: what the phases inside did not book (suspend bookkeeping, call overhead)
         if (!SLICED || __any(alive && !mid)) { // a trip in which no lane finished its segment has nothing to shade
         if (alive) {
@@ -1023,6 +1024,20 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             if ((tp.suspend_lanes > 0 && s->bvh_node_count >= 128) || s->dev.grid_n > 0) kern = c->count_traversal ? trace_kernel<R, false, SCAN_BVH, false, true> : trace_kernel<R, false, SCAN_BVH>;
             else kern = c->count_traversal ? trace_kernel<R, false, SCAN_BVH, false, true, false> : trace_kernel<R, false, SCAN_BVH, false, false, false>;
             dyn_lds = bvh_lds;
+            // The time-sliced sphere kernel keeps its camera-ray stash in LDS too when the scene's tree leaves room for it beside the stack columns (a dead lane reads
+            // its entry with 6 ds_read instead of 11 ds_bpermute, and 14 VGPRs come free): C3 69.30 -> 68.76 ms, C2 3.067 -> 3.040 (RTMI_SPHERE_LDS_STASH=0: the
+            // register stash, which deeper trees -- more than 21 levels with their grid entries -- keep anyway: a fifth kilobyte-row would cost the fourth workgroup per CU)
+            const char *lst_env = std::getenv("RTMI_SPHERE_LDS_STASH");
+            if (!(lst_env && lst_env[0] == '0') && !c->count_traversal && kern == (void (*)(ScenePtr, TraceParams))trace_kernel<R, false, SCAN_BVH>) {
+                const int levels = std::max(4, std::min(RTMI_BVH_STACK, s->bvh_depth + 2));
+                const int words = s->dev.cam_fixed_origin ? 11 : 17;
+                if ((size_t)(levels + RTMI_BVH_SUSPEND_WORDS + words) * kTraceBlock * sizeof(int) <= 40 * 1024) { // four workgroups per CU still fit
+                    kern = trace_kernel<R, false, SCAN_BVH, false, false, true, false, true>;
+                    tp.susp_off = levels * RTMI_BVH_STRIDE;
+                    tp.stash_off = (levels + RTMI_BVH_SUSPEND_WORDS) * RTMI_BVH_STRIDE;
+                    dyn_lds = (size_t)(levels + RTMI_BVH_SUSPEND_WORDS + words) * kTraceBlock * sizeof(int);
+                }
+            }
             break;
         case SCAN_SGPR_CULL: kern = trace_kernel<R, false, SCAN_SGPR_CULL>; break;
         case SCAN_SGPR: kern = trace_kernel<R, false, SCAN_SGPR>; break;
