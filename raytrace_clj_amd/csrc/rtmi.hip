@@ -1018,6 +1018,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             }
             else { kern = trace_kernel<double, false, SCAN_SGPR_CULL, true>; dyn_lds = ext_lds(false, 0); }
         } else
+        const char *lst_env = std::getenv("RTMI_SPHERE_LDS_STASH");
         switch (variant) {
         case SCAN_BVH: // suspend_lanes = 0 or a small tree (< 128 inner nodes) selects the instantiation without the time-slicing machinery (the plain while-while loop);
                        // a scene with an entry grid always runs the time-sliced one (threshold 0 = never park early): the piecewise walk of long segments lives there
@@ -1027,7 +1028,6 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             // The time-sliced sphere kernel keeps its camera-ray stash in LDS too when the scene's tree leaves room for it beside the stack columns (a dead lane reads
             // its entry with 6 ds_read instead of 11 ds_bpermute, and 14 VGPRs come free): C3 69.30 -> 68.76 ms, C2 3.067 -> 3.040 (RTMI_SPHERE_LDS_STASH=0: the
             // register stash, which deeper trees -- more than 21 levels with their grid entries -- keep anyway: a fifth kilobyte-row would cost the fourth workgroup per CU)
-            const char *lst_env = std::getenv("RTMI_SPHERE_LDS_STASH");
             if (!(lst_env && lst_env[0] == '0') && !c->count_traversal && kern == (void (*)(ScenePtr, TraceParams))trace_kernel<R, false, SCAN_BVH>) {
                 const int levels = std::max(4, std::min(RTMI_BVH_STACK, s->bvh_depth + 2));
                 const int words = s->dev.cam_fixed_origin ? 11 : 17;
