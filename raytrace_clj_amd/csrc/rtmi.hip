@@ -995,6 +995,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         // Mixed-kind kernels: LDS = stack columns for THIS scene's tree (its depth is known: the sphere kernels use the compile-time RTMI_BVH_STACK for their
         // immediate ds_ offsets) + the parked cursors (time-sliced instantiation) + the camera-ray stash (11 words per entry, 17 when the rays' origins differ)
         tp.susp_off = RTMI_BVH_STACK * RTMI_BVH_STRIDE; tp.stash_off = 0;
+        const char *lst_env = std::getenv("RTMI_SPHERE_LDS_STASH");
         constexpr bool kExtLdsStash = RTMI_STASH && RTMI_EXT_LDS_STASH && !RTMI_EXT_NO_STASH;
         const int ext_levels = std::max(4, std::min(RTMI_BVH_STACK, s->bvh_depth + 2));
         const int stash_words = kExtLdsStash ? (s->dev.cam_fixed_origin ? 11 : 17) : 0;
@@ -1018,7 +1019,6 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             }
             else { kern = trace_kernel<double, false, SCAN_SGPR_CULL, true>; dyn_lds = ext_lds(false, 0); }
         } else
-        const char *lst_env = std::getenv("RTMI_SPHERE_LDS_STASH");
         switch (variant) {
         case SCAN_BVH: // suspend_lanes = 0 or a small tree (< 128 inner nodes) selects the instantiation without the time-slicing machinery (the plain while-while loop);
                        // a scene with an entry grid always runs the time-sliced one (threshold 0 = never park early): the piecewise walk of long segments lives there
