@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(kTraceBlock, EXT ? ((MSEQ || COUNT) ? 3 : RTMI
                 const int gtile = tp.tile_ids[tile_local];
                 const int x = (gtile % tp.tiles_x) * RTMI_TILE + (l & 7);
                 const int y = (gtile / tp.tiles_x) * RTMI_TILE + (l >> 3);
-                int item = -1;
+                unsigned item = 0xffffffffu; // (an item outside the image / region: an empty entry; work items are 32-bit UNSIGNED -- C4 has 2.1e9 per pass)
                 if (x >= tp.rx0 && x < tp.rx1 && y >= tp.ry0 && y < tp.ry1) {
                     Path<R> Q;
                     start_sample<R>(sc, tp, x, tp.ny - 1 - y, s, Q); // j = ny-1-y (core.clj:105)
@@ -339,18 +339,18 @@ __global__ void __launch_bounds__(kTraceBlock, EXT ? ((MSEQ || COUNT) ? 3 : RTMI
                         best_to_words<R>(Q.oy, w0, w1); lst[13 * kTraceBlock + lane] = w0; lst[14 * kTraceBlock + lane] = w1;
                         best_to_words<R>(Q.oz, w0, w1); lst[15 * kTraceBlock + lane] = w0; lst[16 * kTraceBlock + lane] = w1;
                     }
-                    item = (int)m;
+                    item = m;
                     RTMI_PH(PH_REFILL_GEN)
                 }
-                lst[10 * kTraceBlock + lane] = item;
+                lst[10 * kTraceBlock + lane] = (int)item;
                 s_head = 0u;
             }
             const unsigned avail = 64u - s_head, nd = (unsigned)__popcll(dead);
             const unsigned rank = (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
             if (!alive && rank < avail) {
                 const int e = (int)(s_head + rank);
-                const int item = lst[10 * kTraceBlock + e];
-                if (item >= 0) {
+                const unsigned item = (unsigned)lst[10 * kTraceBlock + e];
+                if (item != 0xffffffffu) {
                     P.dx = best_from_words<R>(lst[e], lst[kTraceBlock + e]); P.dy = best_from_words<R>(lst[2 * kTraceBlock + e], lst[3 * kTraceBlock + e]);
                     P.dz = best_from_words<R>(lst[4 * kTraceBlock + e], lst[5 * kTraceBlock + e]); P.time = best_from_words<R>(lst[6 * kTraceBlock + e], lst[7 * kTraceBlock + e]);
                     P.rs = (u64)(unsigned)lst[8 * kTraceBlock + e] | ((u64)(unsigned)lst[9 * kTraceBlock + e] << 32);
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(kTraceBlock, EXT ? ((MSEQ || COUNT) ? 3 : RTMI
                     }
                     P.ar = P.ag = P.ab = R(1);
                     P.depth = tp.depth;
-                    out_item = (unsigned)item;
+                    out_item = item;
                     alive = true;
                 }
             }
