@@ -50,7 +50,10 @@
 
 (defn- v3 [v] [(mat/mget v 0) (mat/mget v 1) (mat/mget v 2)])
 
-(def ^:private listings (atom 0))         ; counts the media listings of a Hitlist world during flatten-scene's walk
+(def ^:private ^:dynamic *list-ctx* nil)   ; id of the Hitlist context being walked: the outermost Hitlist since the last bvh-node (nil outside any list)
+(def ^:private ^:dynamic *slot* nil)       ; [identity of the list, position] of the list item being walked: a medium's LISTING
+(def ^:private ^:dynamic *poisoned* false) ; a bvh-node INSIDE a Hitlist is among the ancestors: media below it cannot be expressed
+(def ^:private list-ctxs (atom 0))         ; counts the Hitlist contexts of one flatten-scene walk
 (def ^:private media-modes (atom #{}))   ; how flatten-scene's walk reached the media: :descent (bvh-nodes only above) / :hitlist (Hitlists only above)
 
 (defprotocol GpuLeaves
@@ -64,25 +67,29 @@
     hitable.clj:15-26: rtmi_scene_set_media_mode RTMI_MEDIA_HITLIST) or un-narrowed (bvh-node.hit?, hitable.clj:99-105); both at once is
     not supported."))
 
-(defn- leaf [this chain flip] [{:leaf this :chain chain :flip flip}])
+(defn- leaf [this chain flip] [{:leaf this :chain chain :flip flip :list *list-ctx*}])   ; :list -- which Hitlist context the entry stands in (its items are contiguous)
 
 (extend-protocol GpuLeaves
-  Hitlist      (leaves [this c f l b] (doall (mapcat #(leaves % c f true b) (:items this))))                   ; hitable.clj:15-26
-  bvh_node     (leaves [this c f l b] (doall (concat (leaves (:left this) c f l true) (leaves (:right this) c f l true)))) ; hitable.clj:97-105
+  Hitlist      (leaves [this c f l b]                                                                      ; hitable.clj:15-26
+                 ;; the items of a Hitlist (and of the Hitlists nested directly in it) see the closest hit of the items before them: one narrowing context
+                 (binding [*list-ctx* (if (and l *list-ctx*) *list-ctx* (swap! list-ctxs inc))]
+                   (doall (apply concat (map-indexed (fn [i it] (binding [*slot* [(System/identityHashCode this) i]] (doall (leaves it c f true b))))
+                                                     (:items this))))))
+  bvh_node     (leaves [this c f l b]                                                                      ; hitable.clj:97-105: both children, the un-narrowed interval
+                 (binding [*list-ctx* nil *slot* nil *poisoned* (or *poisoned* (boolean l))]
+                   (doall (concat (leaves (:left this) c f false true) (leaves (:right this) c f false true)))))
   Box          (leaves [this c f l b] (leaves (:sides this) c f l b))   ; hitable.clj:491-494: (hit? sides ...) with the caller's interval
   FlipNormals  (leaves [this c f l b] (leaves (:item this) c (bit-xor f 1) l b))                             ; hitable.clj:375-381
   Translate    (leaves [this c f l b] (leaves (:item this) (conj c (into [0.0] (v3 (:offset this)))) f l b)) ; hitable.clj:391-396
   RotateY      (leaves [this c f l b] (leaves (:obj this) (conj c [1.0 (:sin-theta this) (:cos-theta this) 0.0]) f l b)) ; :410-450
   ConstantMedium (leaves [this c f l b]                                                                      ; hitable.clj:516-541
-                   (when (and l b)
-                     (throw (ex-info "a ConstantMedium inside a Hitlist below a bvh-node is not supported on the GPU path"
+                   (when *poisoned*
+                     (throw (ex-info "a ConstantMedium below a bvh-node that itself sits inside a Hitlist is not supported on the GPU path"
                                      {:unsupported-on-gpu-path ConstantMedium})))
-                   (swap! media-modes conj (if l :hitlist :descent))
-                   ;; a Hitlist world: WHERE a medium stands in the list decides the t-max it is handed (hitable.clj:15-26), so every LISTING of
-                   ;; the record is a primitive of its own (:listing n keeps dedup-leaves from folding a second listing into the first)
-                   (if l
-                     [{:leaf this :chain c :flip f :listing (swap! listings inc)}]
-                     (leaf this c f)))
+                   (swap! media-modes conj (cond (and l b) :narrowed l :hitlist :else :descent))
+                   ;; inside a Hitlist WHERE a medium stands decides the t-max it is handed (hitable.clj:15-26): every LISTING of the record is a primitive of
+                   ;; its own (:listing = the list item's slot: the same listing reached twice by the descent -- a one-item make-bvh -- is one primitive asked twice)
+                   [{:leaf this :chain c :flip f :list *list-ctx* :listing (when l *slot*)}])
   Sphere       (leaves [this c f l b] (leaf this c f))
   UVSphere     (leaves [this c f l b] (leaf this c f))
   MovingSphere (leaves [this c f l b] (leaf this c f))
@@ -175,7 +182,7 @@
   "{:camera c :world w} -> the flat arrays of include/rtmi.h (as Clojure primitive arrays)"
   [{:keys [camera world]}]
   (reset! images [])
-  (reset! listings 0)
+  (reset! list-ctxs 0)
   (reset! media-modes #{})
   (let [called    (vec (leaves world [] 0 false false))    ; hit? invocation order, repeats included
         _         (when (> (count @media-modes) 1)
@@ -185,7 +192,11 @@
         world-es  (dedup-leaves lid called)
         key-of    (fn [e] [(lid (:leaf e)) (:chain e) (:flip e) (:listing e)])
         index-of  (zipmap (map key-of world-es) (range))
-        media-calls (mapv #(index-of (key-of %)) (filter #(instance? ConstantMedium (:leaf %)) called))
+        called-media (filterv #(instance? ConstantMedium (:leaf %)) called)
+        media-calls (mapv #(index-of (key-of %)) called-media)
+        ;; per call: the first primitive of the Hitlist items that narrow it (rtmi_scene_set_media_calls_narrowed); its own index: none (reached through bvh-nodes only)
+        first-of  (reduce (fn [m [i e]] (if (and (:list e) (not (contains? m (:list e)))) (assoc m (:list e) i) m)) {} (map-indexed vector world-es))
+        media-narrow-from (mapv (fn [e] (if (:listing e) (first-of (:list e)) (index-of (key-of e)))) called-media)
         ;; every medium's boundary is flattened on its own and appended AFTER the world (kind | 16)
         bounds    (reduce (fn [acc [i e]]
                             (if (instance? ConstantMedium (:leaf e))
@@ -241,7 +252,9 @@
      :xform-kind  (int-array (map #(int (first %)) xforms))
      :xform-param (double-array (mapcat rest xforms))
      :media-calls (int-array media-calls)
-     :media-mode  (int (if (= @media-modes #{:hitlist}) 1 0))   ; RTMI_MEDIA_HITLIST: the world is a Hitlist, its narrowing reaches the media
+     :media-narrow-from (int-array media-narrow-from)
+     ;; 1 = RTMI_MEDIA_HITLIST: the world is a Hitlist, its narrowing reaches every medium; 2 = narrowed per call: Hitlists holding media below bvh-nodes
+     :media-mode  (int (cond (= @media-modes #{:hitlist}) 1 (or (:narrowed @media-modes) (:hitlist @media-modes)) 2 :else 0))
      :uses-perlin (boolean (some #(#{3 4 5} (:kind %)) trows))
      :images      @images}))
 
@@ -277,11 +290,15 @@
                                            (unchecked-byte (bit-and 0xff (bit-shift-right p sh)))))
                                        imgs))]
           (check (call-int "rtmi_scene_set_images" scene (int (count imgs)) wh px))))
-      (when (pos? (alength ^ints (:media-calls f)))
+      (if (= 2 (:media-mode f))
         (let [calls (:media-calls f)]
-          (check (call-int "rtmi_scene_set_media_calls" scene (int (alength ^ints calls)) calls))))
-      (when (pos? (:media-mode f))
-        (check (call-int "rtmi_scene_set_media_mode" scene (int (:media-mode f)))))
+          (check (call-int "rtmi_scene_set_media_calls_narrowed" scene (int (alength ^ints calls)) calls (:media-narrow-from f))))
+        (do
+          (when (pos? (alength ^ints (:media-calls f)))
+            (let [calls (:media-calls f)]
+              (check (call-int "rtmi_scene_set_media_calls" scene (int (alength ^ints calls)) calls))))
+          (when (pos? (:media-mode f))
+            (check (call-int "rtmi_scene_set_media_mode" scene (int (:media-mode f)))))))
       scene)))
 
 (defn render

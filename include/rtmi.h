@@ -159,6 +159,13 @@ int rtmi_scene_set_media_calls(rtmi_scene *scene, int32_t n_calls, const int32_t
  * A world that mixes the two (a Hitlist holding media below a bvh-node) is not supported: the flatteners raise "unsupported on GPU path". */
 enum { RTMI_MEDIA_DESCENT = 0, RTMI_MEDIA_HITLIST = 1 };
 int rtmi_scene_set_media_mode(rtmi_scene *scene, int32_t mode);
+/* The general form (round 4): Hitlists holding media BELOW bvh-nodes.  calls = the media call sequence as for rtmi_scene_set_media_calls; narrow_from[k] = the
+ * first primitive of the Hitlist items that stand before call k's medium in its own (possibly nested) Hitlist -- Hitlist.hit? hands the medium the closest hit
+ * among primitives [narrow_from[k], calls[k]) as its t-max (hitable.clj:15-26), whatever the bvh-nodes above that Hitlist do (they pass the interval on
+ * un-narrowed, hitable.clj:99-105); narrow_from[k] = calls[k]: no item narrows it (a medium reached through bvh-nodes only).  The items of a Hitlist are
+ * contiguous in the flattened order; calls that share a narrowing list come in list order.  Replaces both calls above for such worlds; still unsupported: a
+ * bvh-node BETWEEN a narrowing Hitlist and its medium, a medium inside a medium's boundary. */
+int rtmi_scene_set_media_calls_narrowed(rtmi_scene *scene, int32_t n_calls, const int32_t *calls, const int32_t *narrow_from);
 /* HBM bytes the scene occupies (everything its creation uploaded: records, tree, tables) -- bench.py's `upload_bytes` */
 int rtmi_scene_device_bytes(rtmi_scene *scene, int64_t *out_bytes);
 int rtmi_scene_destroy(rtmi_scene *scene);

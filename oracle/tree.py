@@ -14,14 +14,9 @@ from raytrace_clj_amd import hitable as H
 
 
 def attach_tree(flat, world):
-    leaves = []
-    fl._leaves(world, leaves, set())  # world primitives only (media included, their boundaries not)
-    prim_index, medium_listings, listing_seen = {}, {}, {}
-    for i, (o, chain, flip) in enumerate(leaves):
-        key = (id(o), chain, flip)
-        if isinstance(o, H.ConstantMedium):  # a Hitlist world lists a medium as often as it stands in the list: the k-th visit of the walk below is its k-th primitive
-            medium_listings.setdefault(key, []).append(i)
-        prim_index.setdefault(key, i)
+    leaves, keys = [], []
+    fl._leaves(world, leaves, set(), keys=keys)  # world primitives only (media included, their boundaries not); keys: what every entry was recorded under
+    prim_index = {k: i for i, k in enumerate(keys)}
     mat_of_prim = flat.prim_mat
     kind, a, d, prim, children = [], [], [], [], []
 
@@ -37,18 +32,19 @@ def attach_tree(flat, world):
 
     state = {"boundary": False}
 
-    def walk(o, chain, flip, boundary=False):
+    def walk(o, chain, flip, boundary=False, in_list=False, slot=None):
         if boundary:
             state["boundary"] = True
             try:
                 return walk(o, chain, flip)
             finally:
                 state["boundary"] = False
+        lid = id(o)  # (the flattener keys a medium's listing by the list OBJECT it stands in and its position there)
         if isinstance(o, (list, tuple)):
             o = H.Hitlist(list(o))
         if isinstance(o, H.Hitlist):
             n = new(N_HITLIST)
-            ids = [walk(it, chain, flip) for it in o.items]
+            ids = [walk(it, chain, flip, False, True, (lid, i)) for i, it in enumerate(o.items)]
             a[n] = [len(children), len(ids), 0]
             children.extend(ids)
             return n
@@ -60,25 +56,22 @@ def attach_tree(flat, world):
             return n
         if isinstance(o, H.Box):
             n = new(N_BOX, dd=list(o.p0) + list(o.p1))
-            a[n] = [walk(o.sides, chain, flip), 0, 0]
+            a[n] = [walk(o.sides, chain, flip, False, in_list, slot), 0, 0]
             return n
         if isinstance(o, H.FlipNormals):
             n = new(N_FLIP)
-            a[n] = [walk(o.item, chain, flip ^ 1), 0, 0]
+            a[n] = [walk(o.item, chain, flip ^ 1, False, in_list, slot), 0, 0]
             return n
         if isinstance(o, H.Translate):
             n = new(N_TRANSLATE, dd=list(o.offset))
-            a[n] = [walk(o.item, chain + ((fl.XFORM_TRANSLATE, tuple(float(v) for v in o.offset)),), flip), 0, 0]
+            a[n] = [walk(o.item, chain + ((fl.XFORM_TRANSLATE, tuple(float(v) for v in o.offset)),), flip, False, in_list, slot), 0, 0]
             return n
         if isinstance(o, H.RotateY):
             n = new(N_ROTATE_Y, dd=[o.sin_theta, o.cos_theta])
-            a[n] = [walk(o.obj, chain + ((fl.XFORM_ROTATE_Y, (float(o.sin_theta), float(o.cos_theta), 0.0)),), flip), 0, 0]
+            a[n] = [walk(o.obj, chain + ((fl.XFORM_ROTATE_Y, (float(o.sin_theta), float(o.cos_theta), 0.0)),), flip, False, in_list, slot), 0, 0]
             return n
         if isinstance(o, H.ConstantMedium):
-            key = (id(o), chain, flip)
-            k = listing_seen.get(key, 0)
-            listing_seen[key] = k + 1
-            i = medium_listings[key][min(k, len(medium_listings[key]) - 1)]  # (bvh-node worlds de-duplicate: one primitive however often the descent reaches it)
+            i = prim_index[(id(o), chain, flip) + ((slot,) if in_list else ())]  # a medium's LISTING in a Hitlist is a primitive of its own
             n = new(N_MEDIUM, dd=[o.density], p=i)
             a[n] = [walk(o.boundary, chain, flip, boundary=True), 0, int(mat_of_prim[i])]
             return n

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("RTMI_LIB") or os.path.join(_HERE, "lib", "librtmi.so"
 # every symbol include/rtmi.h declares
 SYMBOLS = [
     "rtmi_last_error", "rtmi_backend_name", "rtmi_version", "rtmi_init", "rtmi_shutdown", "rtmi_set_option",
-    "rtmi_device_info", "rtmi_scene_create", "rtmi_scene_create_ex", "rtmi_scene_set_perlin", "rtmi_scene_set_images", "rtmi_scene_set_media_calls", "rtmi_scene_set_media_mode", "rtmi_scene_device_bytes", "rtmi_scene_destroy", "rtmi_render", "rtmi_render_device",
+    "rtmi_device_info", "rtmi_scene_create", "rtmi_scene_create_ex", "rtmi_scene_set_perlin", "rtmi_scene_set_images", "rtmi_scene_set_media_calls", "rtmi_scene_set_media_mode", "rtmi_scene_set_media_calls_narrowed", "rtmi_scene_device_bytes", "rtmi_scene_destroy", "rtmi_render", "rtmi_render_device",
     "rtmi_render_tiles_device", "rtmi_local_tiles", "rtmi_assemble_device", "rtmi_last_trace_ms", "rtmi_last_reduce_ms", "rtmi_probe_hit",
     "rtmi_probe_paths", "rtmi_probe_camera", "rtmi_probe_texture", "rtmi_probe_scatter", "rtmi_probe_rng",
     "rtmi_sample_key", "rtmi_test_half_outward", "rtmi_test_build_tree", "rtmi_probe_arith", "rtmi_probe_math", "rtmi_probe_math2", "rtmi_last_traversal_counters",
@@ -68,6 +68,7 @@ def lib():
     L.rtmi_scene_set_images.argtypes = [vp, i32, vp, vp]
     L.rtmi_scene_set_media_calls.argtypes = [vp, i32, vp]
     L.rtmi_scene_set_media_mode.argtypes = [vp, i32]
+    L.rtmi_scene_set_media_calls_narrowed.argtypes = [vp, i32, vp, vp]
     L.rtmi_scene_device_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
     L.rtmi_scene_destroy.argtypes = [vp]
     L.rtmi_render.argtypes = [vp, i32, i32, i32, i32, u64, i32, i32, i32, i32, i32, vp, vp, vp]

@@ -120,10 +120,14 @@ class DeviceScene:
             perm = np.ascontiguousarray(f.perlin_perm, np.int32)
             check(_ffi.lib().rtmi_scene_set_perlin(h, ptr(vec), ptr(perm)))
         calls = getattr(f, "media_calls", None)
-        if calls is not None and len(calls):  # ConstantMedium hit? invocation order (a medium in a one-item bvh leaf is asked twice)
+        if calls is not None and len(calls) and getattr(f, "media_mode", 0) == 2:  # Hitlists holding media below bvh-nodes: the call sequence with its narrowing ranges
+            calls = np.ascontiguousarray(calls, np.int32)
+            lo = np.ascontiguousarray(f.media_narrow_from, np.int32)
+            check(_ffi.lib().rtmi_scene_set_media_calls_narrowed(h, len(calls), ptr(calls), ptr(lo)))
+        elif calls is not None and len(calls):  # ConstantMedium hit? invocation order (a medium in a one-item bvh leaf is asked twice)
             calls = np.ascontiguousarray(calls, np.int32)
             check(_ffi.lib().rtmi_scene_set_media_calls(h, len(calls), ptr(calls)))
-        if getattr(f, "media_mode", 0):  # the world is a Hitlist holding media: their hit? sees the t-max narrowed by the items before them
+        if getattr(f, "media_mode", 0) == 1:  # the world is a Hitlist holding media: their hit? sees the t-max narrowed by the items before them
             check(_ffi.lib().rtmi_scene_set_media_mode(h, int(f.media_mode)))
         images = getattr(f, "images", None) or []
         if images:  # ImageMap pixels (texture.clj:126-133)

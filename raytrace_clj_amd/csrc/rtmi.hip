@@ -142,6 +142,32 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
     if (!active) return;
     const double a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
     ExtHit H = {tmax, 0x7fffffff, -1, false};
+    if (MSEQ && sc.media_seq == 2) {
+        // RTMI_MEDIA_NARROWED: Hitlists holding media BELOW bvh-nodes (round 4).  A bvh-node hands its children the un-narrowed interval (hitable.clj:99-105), a Hitlist
+        // hands every item the closest hit of the items before it (hitable.clj:15-26): call k of the media sequence sees the closest hit among the primitives
+        // [media_lo[k], media_idx[k]) -- the items before it in its own (possibly nested) Hitlist -- or the caller's t-max when that range is empty.  The items of one
+        // Hitlist are contiguous in the flattened order, so the narrowing state is a running closest hit over that list: its surfaces are scanned piece by piece
+        // between its media (index-restricted scan: such lists are short), every medium's candidate joins it.  The world's closest hit is then the fold of ALL
+        // surfaces (one traversal, below) and of the media's candidates -- in any order (ExtHit).
+        MediumChord chord; chord.idx = -1; chord.ok = false; chord.t1 = chord.t2 = chord.mag = 0.0;
+        ExtHit Hrun = {tmax, 0x7fffffff, -1, false};
+        int cur_lo = -1, scanned_to = 0;
+        for (int k = 0; k < sc.n_media; ++k) {
+            const int m = sc.media_idx[k], lo = sc.media_lo[k];
+            if (lo >= m) { ext_medium_test(sc, m, P, tmin, tmax, H, chord, COUNT ? cnt : nullptr); continue; } // un-narrowed: a medium reached through bvh-nodes only
+            if (lo != cur_lo) { Hrun.t = tmax; Hrun.F = 0x7fffffff; Hrun.W = -1; Hrun.any = false; cur_lo = lo; scanned_to = lo; }
+            if (m > scanned_to) scan_all_cull_ext(sc, P, a, tmin, Hrun, scanned_to, m);
+            double tm = 0.0;
+            if (ext_medium_test(sc, m, P, tmin, Hrun.any ? Hrun.t : tmax, Hrun, chord, COUNT ? cnt : nullptr, &tm)) ext_update(H, tm, m, true);
+            scanned_to = m + 1;
+        }
+        if (bvh) scan_bvh_ext<false, COUNT>(sc, stack, P, a, tmin, H, nullptr, false, 0, cnt);
+        else if (sc.small_scan) scan_small_ext(sc, P, tmin, H);
+        else scan_all_cull_ext(sc, P, a, tmin, H);
+        best_i = ext_winner(H);
+        if (best_i >= 0) best_t = H.t;
+        return;
+    }
     if (MSEQ) {
         // RTMI_MEDIA_HITLIST: the world is a Hitlist (hitable.clj:15-26: (hit? item r t-min closest-so-far), item after item).  Surfaces may be
         // folded in any order (ExtHit reproduces the list's tie rule), so the list is scanned in pieces: the surfaces before the first medium,
@@ -819,7 +845,7 @@ struct rtmi_scene {
     std::vector<int> host_kind; // primitive kinds (boundary flag removed), for argument checks
     // the caller's arrays, copied at creation (the library keeps no host POINTERS): what rtmi_scene_clone replicates
     struct Args {
-        std::vector<int32_t> prim_kind, prim_mat, mat_kind, mat_tex, tex_kind, tex_child, prim_flip, prim_xform, xform_kind, perm, media_calls, image_wh;
+        std::vector<int32_t> prim_kind, prim_mat, mat_kind, mat_tex, tex_kind, tex_child, prim_flip, prim_xform, xform_kind, perm, media_calls, media_lo, image_wh;
         std::vector<double> prim_geom, mat_param, tex_param, cam, xform_param, perlin_vec;
         std::vector<uint8_t> image_rgb;
         int cam_kind = 0;
@@ -2092,7 +2118,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     }
     d.n_all = n_world; d.cull_t_lo = t_lo; d.cull_t_hi = t_hi; // the scans walk the world; boundary primitives are reached only through their medium
     d.n_media = n_media;
-    for (int k = 0; k < n_media; ++k) d.media_idx[k] = media[k];
+    for (int k = 0; k < n_media; ++k) { d.media_idx[k] = media[k]; d.media_lo[k] = media[k]; }
     s->host_kind = pk;
     std::vector<int> grid_cells;
     const double t_create1 = now_ms();
@@ -2294,11 +2320,32 @@ RTMI_EXPORT int rtmi_scene_set_media_calls(rtmi_scene *s, int32_t n_calls, const
     if (n_calls < 0 || n_calls > 32 || (n_calls > 0 && !calls)) return fail(RTMI_E_ARG, "n_calls must be 0..32");
     for (int k = 0; k < n_calls; ++k)
         if (calls[k] < 0 || calls[k] >= s->n_prims || s->host_kind[(size_t)calls[k]] != RTMI_PRIM_MEDIUM) return fail(RTMI_E_ARG, "calls[%d] = %d is not a medium primitive", k, calls[k]);
-    if (s->dev.media_seq)
+    if (s->dev.media_seq == 1)
         for (int k = 1; k < n_calls; ++k) if (calls[k] <= calls[k - 1]) return fail(RTMI_E_ARG, "RTMI_MEDIA_HITLIST: the media must be called once each, in ascending primitive (= list) order");
+    if (s->dev.media_seq == 2) { s->dev.media_seq = 0; s->args.media_mode = 0; } // a plain call sequence replaces a narrowed one
     s->dev.n_media = n_calls;
-    for (int k = 0; k < n_calls; ++k) s->dev.media_idx[k] = calls[k];
+    for (int k = 0; k < n_calls; ++k) { s->dev.media_idx[k] = calls[k]; s->dev.media_lo[k] = calls[k]; }
     s->args.media_calls.assign(calls, calls + n_calls); s->args.has_media_calls = true;
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    return reupload_descriptor(s);
+}
+
+// RTMI_MEDIA_NARROWED: the media call sequence with, per call, the first primitive of the Hitlist items that narrow its t-max (narrow_from[k] = calls[k]: none)
+RTMI_EXPORT int rtmi_scene_set_media_calls_narrowed(rtmi_scene *s, int32_t n_calls, const int32_t *calls, const int32_t *narrow_from) {
+    if (!scene_ok(s)) return fail(RTMI_E_STATE, "invalid scene handle");
+    if (n_calls < 0 || n_calls > 32 || (n_calls > 0 && (!calls || !narrow_from))) return fail(RTMI_E_ARG, "n_calls must be 0..32");
+    for (int k = 0; k < n_calls; ++k) {
+        if (calls[k] < 0 || calls[k] >= s->n_prims || s->host_kind[(size_t)calls[k]] != RTMI_PRIM_MEDIUM) return fail(RTMI_E_ARG, "calls[%d] = %d is not a medium primitive", k, calls[k]);
+        if (narrow_from[k] < 0 || narrow_from[k] > calls[k]) return fail(RTMI_E_ARG, "narrow_from[%d] = %d must lie in [0, calls[%d] = %d]", k, narrow_from[k], k, calls[k]);
+        if (k > 0 && narrow_from[k] < calls[k] && narrow_from[k] == narrow_from[k - 1] && calls[k] <= calls[k - 1])
+            return fail(RTMI_E_ARG, "calls %d and %d share a narrowing Hitlist and must come in list order", k - 1, k);
+    }
+    s->dev.n_media = n_calls;
+    bool any = false;
+    for (int k = 0; k < n_calls; ++k) { s->dev.media_idx[k] = calls[k]; s->dev.media_lo[k] = narrow_from[k]; any = any || narrow_from[k] < calls[k]; }
+    s->dev.media_seq = any ? 2 : 0;
+    s->args.media_calls.assign(calls, calls + n_calls); s->args.media_lo.assign(narrow_from, narrow_from + n_calls); s->args.has_media_calls = true;
+    s->args.media_mode = any ? 2 : 0;
     HIP_TRY(hipSetDevice(s->ctx->device));
     return reupload_descriptor(s);
 }
@@ -2457,8 +2504,11 @@ RTMI_EXPORT int rtmi_scene_clone(rtmi_scene *src, rtmi_ctx *ctx, rtmi_scene **ou
     if (rc) return rc;
     if (!rc && !A.perlin_vec.empty()) rc = rtmi_scene_set_perlin(s, A.perlin_vec.data(), A.perm.data());
     if (!rc && !A.image_wh.empty()) rc = rtmi_scene_set_images(s, (int32_t)(A.image_wh.size() / 2), A.image_wh.data(), A.image_rgb.data());
-    if (!rc && A.has_media_calls) rc = rtmi_scene_set_media_calls(s, (int32_t)A.media_calls.size(), A.media_calls.data());
-    if (!rc && A.media_mode) rc = rtmi_scene_set_media_mode(s, A.media_mode);
+    if (!rc && A.has_media_calls && A.media_mode == 2) rc = rtmi_scene_set_media_calls_narrowed(s, (int32_t)A.media_calls.size(), A.media_calls.data(), A.media_lo.data());
+    else {
+        if (!rc && A.has_media_calls) rc = rtmi_scene_set_media_calls(s, (int32_t)A.media_calls.size(), A.media_calls.data());
+        if (!rc && A.media_mode) rc = rtmi_scene_set_media_mode(s, A.media_mode);
+    }
     if (rc) { const std::string keep = g_err; rtmi_scene_destroy(s); g_err = keep; return rc; }
     *out_scene = s;
     return RTMI_OK;

@@ -65,6 +65,8 @@ struct DevScene {
     int n_mloc;              // number of such regions (media whose boundary box holds less than half of the tree's primitives)
     int mloc_root[4];        // root code of the region's tree (RTMI_BVH_EMPTY: no surface reaches into it)
     float mloc_box[4][6];    // lo.xyz hi.xyz: every surface point inside this box belongs to a primitive of the region's tree (the device shrinks it by the float error of a ray's end points)
+    int media_lo[32];        // RTMI_MEDIA_NARROWED (media_seq = 2): per call of media_idx, the first primitive of the Hitlist items that narrow its t-max -- the call sees the
+                             // closest hit among primitives [media_lo[k], media_idx[k]) (hitable.clj:15-26 inside a Hitlist that sits below bvh-nodes); = media_idx[k]: un-narrowed
     int media_seq;           // RTMI_MEDIA_HITLIST: the world is a Hitlist (hitable.clj:15-26), a medium's hit? sees the t-max narrowed by the items before it
     int n_media;             // hit? invocations of ConstantMedium primitives (hitable.clj:516) per ray, in the reference's call order
     int media_idx[32];       // (a medium may appear twice: rtmi_scene_set_media_calls); exact12 = density, first boundary prim, count
@@ -1634,18 +1636,23 @@ __device__ inline void ext_medium_chord(SceneRef sc, int idx, const Path<double>
     C.mag = rt_sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
     C.t1 = h1.t; C.t2 = h2.t; C.ok = true;
 }
-__device__ inline void ext_medium_test(SceneRef sc, int idx, Path<double> &P, double tmin, double tmax, ExtHit &H, MediumChord &C, unsigned *cnt = nullptr) {
+// hit_t (optional): receives the medium's hit parameter when it hits (the return value says whether)
+__device__ inline bool ext_medium_test(SceneRef sc, int idx, Path<double> &P, double tmin, double tmax, ExtHit &H, MediumChord &C, unsigned *cnt = nullptr, double *hit_t = nullptr) {
     if (C.idx != idx) ext_medium_chord(sc, idx, P, C, cnt); // (wave-uniform)
-    if (!C.ok) return;
+    if (!C.ok) return false;
     double t1 = C.t1, t2 = C.t2;
     if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
-    if (!(t1 < t2)) return;
+    if (!(t1 < t2)) return false;
     if (t1 < 0.0) t1 = 0.0;
     const double density = ext_ld<true>(sc.exact12, (size_t)idx * 12);
     const double dist_in = (t2 - t1) * C.mag;
     const double hit_distance = -(rt_log_unit(next_uniform(P)) / density);
-    if (hit_distance < dist_in) ext_update(H, t1 + hit_distance / C.mag, idx, true);
+    if (!(hit_distance < dist_in)) return false;
+    const double t = t1 + hit_distance / C.mag;
+    ext_update(H, t, idx, true);
+    if (hit_t) *hit_t = t;
+    return true;
 }
 
 // ---- a tree leaf's exact test from ONE record ------------------------------------------------------------------------------------------------

@@ -57,7 +57,8 @@ class FlatScene:
         self.images = []            # [h, w, 3] uint8 arrays; TEX_IMAGE's first parameter indexes this list
         # ConstantMedium: the primitive indices of the media in the order (and multiplicity) the reference's descent calls their hit?
         self.media_calls = np.zeros(0, np.int32)
-        self.media_mode = 0  # RTMI_MEDIA_DESCENT (bvh-node descent, un-narrowed t-max) | 1 = RTMI_MEDIA_HITLIST (the world is a Hitlist)
+        self.media_mode = 0  # RTMI_MEDIA_DESCENT (bvh-node descent, un-narrowed t-max) | 1 = RTMI_MEDIA_HITLIST (the world is a Hitlist) | 2 = narrowed per call
+        self.media_narrow_from = np.zeros(0, np.int32)  # per media call: first primitive of the Hitlist items that narrow it (= the medium's own index: none)
 
     n_world = None  # primitives [0, n_world) are the world; the rest are medium boundaries (None: all of them are the world)
 
@@ -69,57 +70,60 @@ class FlatScene:
 _LEAF_TYPES = (hit.Sphere, hit.UVSphere, hit.MovingSphere, hit.RectXY, hit.RectXZ, hit.RectYZ, hit.Triangle)
 
 
-def _leaves(world, out, seen, chain=(), flip=0, in_list=False, calls=None, under_bvh=False, modes=None):
-    """out gets (leaf, chain, flip): chain = the Translate/RotateY wrappers around the leaf, outermost first.
-    calls (optional list) gets the key of every ConstantMedium in the order, and as often as, the reference's descent calls
+def _leaves(world, out, seen, chain=(), flip=0, in_list=False, calls=None, under_bvh=False, modes=None, ctx=None, slot=None, keys=None):
+    """out gets (leaf, chain, flip): chain = the Translate/RotateY wrappers around the leaf, outermost first; keys (optional list, in step with out) the key every
+    entry was recorded under.
+    calls (optional list) gets (key, narrow_from) of every ConstantMedium in the order, and as often as, the reference's descent calls
     its hit?: make-bvh stores a lone item as bvh-node(L, L) (hitable.clj:113-114) and bvh-node.hit? evaluates both children
-    (hitable.clj:101-102), so such a subtree is visited twice per ray -- harmless for surfaces, two random draws for a medium.
-    modes (optional set) collects how the media are reached: "descent" (only bvh-nodes / wrappers above: un-narrowed t-max,
-    hitable.clj:99-105) or "hitlist" (only Hitlists / wrappers above: the t-max narrowed by the items before it, hitable.clj:15-26)."""
-    if isinstance(world, hit.Hitlist):
-        for it in world.items:
-            _leaves(it, out, seen, chain, flip, True, calls, under_bvh, modes)
+    (hitable.clj:101-102), so such a subtree is visited twice per ray -- harmless for surfaces, two random draws for a medium.  narrow_from = index (in out) of
+    the first item of the Hitlist context the medium stands in: Hitlist.hit? hands it the closest hit of the items before it (hitable.clj:15-26); None = un-narrowed.
+    modes (optional set) collects how the media are reached: "descent" (only bvh-nodes / wrappers above: un-narrowed t-max, hitable.clj:99-105), "hitlist" (only
+    Hitlists / wrappers above) or "narrowed" (a Hitlist below bvh-nodes: round 4).
+    ctx: the Hitlist context ({"lo": index of its first primitive, "dup": a shared record was skipped inside it}); slot: (id of the list, position) of the list
+    item being walked -- a medium's LISTING: the same record listed twice in a list is two primitives, the same listing reached twice by the descent is one."""
+    if isinstance(world, (hit.Hitlist, list, tuple)):
+        items = world.items if isinstance(world, hit.Hitlist) else world
+        inner = ctx if (in_list and ctx is not None) else {"lo": len(out), "dup": False, "poisoned": bool(ctx and ctx.get("poisoned"))}
+        for i, it in enumerate(items):
+            _leaves(it, out, seen, chain, flip, True, calls, under_bvh, modes, inner, (id(world), i), keys)
     elif isinstance(world, hit.ConstantMedium):
-        if in_list and under_bvh:
-            raise UnsupportedOnGpuPath("a ConstantMedium inside a Hitlist that sits below a bvh-node is not supported on the GPU path (its t-max is "
-                                       "narrowed by some siblings and not by others): make the world one Hitlist, or one make-bvh tree")
+        if ctx is not None and ctx.get("poisoned"):
+            raise UnsupportedOnGpuPath("a ConstantMedium below a bvh-node that itself sits inside a Hitlist is not supported on the GPU path (its t-max is narrowed by "
+                                       "the list's earlier items but not by its bvh siblings)")
         if modes is not None:
-            modes.add("hitlist" if in_list else "descent")
-        key = (id(world), chain, flip)
-        if in_list:
-            # a Hitlist world: WHERE a medium stands in the list decides the t-max it is handed (hitable.clj:15-26), so every LISTING of the record is a
-            # primitive of its own at its own place (the same record listed twice draws twice, each time narrowed by the items before that listing)
-            occ = sum(1 for k in seen if k[:3] == key and len(k) == 4)
-            key = key + (occ,)
-            seen.add(key)
-            out.append((world, chain, flip))
-            if calls is not None:
-                calls.append(key)
-            return
-        if calls is not None:
-            calls.append(key)
+            modes.add(("narrowed" if under_bvh else "hitlist") if in_list else "descent")
+        key = (id(world), chain, flip) + ((slot,) if in_list else ())
         if key not in seen:
+            if in_list and ctx["dup"]:
+                raise UnsupportedOnGpuPath("a Hitlist that holds a ConstantMedium shares a record with another part of the world: its items are not contiguous in the "
+                                           "flattened order, so the medium's narrowing cannot be expressed on the GPU path")
             seen.add(key)
             out.append((world, chain, flip))
+            if keys is not None:
+                keys.append(key)
+        if calls is not None:
+            calls.append((key, ctx["lo"] if in_list else None))
     elif isinstance(world, hit.bvh_node):
-        _leaves(world.left, out, seen, chain, flip, in_list, calls, True, modes)
-        _leaves(world.right, out, seen, chain, flip, in_list, calls, True, modes)
+        below = {"lo": None, "dup": False, "poisoned": True} if in_list else None  # a bvh-node INSIDE a Hitlist: media below it are narrowed by some siblings only
+        _leaves(world.left, out, seen, chain, flip, False, calls, True, modes, below, None, keys)
+        _leaves(world.right, out, seen, chain, flip, False, calls, True, modes, below, None, keys)
     elif isinstance(world, hit.Box):
-        _leaves(world.sides, out, seen, chain, flip, in_list, calls, under_bvh, modes)  # (hit? sides ...) with the caller's interval: its six rectangles splice into the enclosing list
+        _leaves(world.sides, out, seen, chain, flip, in_list, calls, under_bvh, modes, ctx, slot, keys)  # (hit? sides ...) with the caller's interval: its six rectangles splice into the enclosing list
     elif isinstance(world, hit.FlipNormals):
-        _leaves(world.item, out, seen, chain, flip ^ 1, in_list, calls, under_bvh, modes)
+        _leaves(world.item, out, seen, chain, flip ^ 1, in_list, calls, under_bvh, modes, ctx, slot, keys)
     elif isinstance(world, hit.Translate):
-        _leaves(world.item, out, seen, chain + ((XFORM_TRANSLATE, tuple(float(v) for v in world.offset)),), flip, in_list, calls, under_bvh, modes)
+        _leaves(world.item, out, seen, chain + ((XFORM_TRANSLATE, tuple(float(v) for v in world.offset)),), flip, in_list, calls, under_bvh, modes, ctx, slot, keys)
     elif isinstance(world, hit.RotateY):
-        _leaves(world.obj, out, seen, chain + ((XFORM_ROTATE_Y, (float(world.sin_theta), float(world.cos_theta), 0.0)),), flip, in_list, calls, under_bvh, modes)
+        _leaves(world.obj, out, seen, chain + ((XFORM_ROTATE_Y, (float(world.sin_theta), float(world.cos_theta), 0.0)),), flip, in_list, calls, under_bvh, modes, ctx, slot, keys)
     elif isinstance(world, _LEAF_TYPES):
         key = (id(world), chain, flip)  # the same record under two different instances is two primitives
         if key not in seen:
             seen.add(key)
             out.append((world, chain, flip))
-    elif isinstance(world, (list, tuple)):
-        for it in world:
-            _leaves(it, out, seen, chain, flip, True, calls, under_bvh, modes)
+            if keys is not None:
+                keys.append(key)
+        elif in_list and ctx is not None:
+            ctx["dup"] = True
     else:
         raise UnsupportedOnGpuPath("%s is not supported on the GPU path" % type(world).__name__)
 
@@ -144,10 +148,8 @@ def flatten(scene_or_world, camera=None, perlin_seed=None):
         world, camera = scene_or_world["world"], scene_or_world["camera"]
     else:
         world = scene_or_world
-    leaves, medium_calls, modes = [], [], set()
-    _leaves(world, leaves, set(), calls=medium_calls, modes=modes)
-    if len(modes) > 1:
-        raise UnsupportedOnGpuPath("the world reaches some ConstantMedium records through a Hitlist and others through bvh-nodes only: not supported on the GPU path")
+    leaves, medium_calls, modes, keys = [], [], set(), []
+    _leaves(world, leaves, set(), calls=medium_calls, modes=modes, keys=keys)
 
     textures, materials = _Interner(), _Interner()
     uses, images = {"perlin": False}, []
@@ -210,16 +212,12 @@ def flatten(scene_or_world, camera=None, perlin_seed=None):
             leaves.extend(b)
     fs = FlatScene()
     fs.n_world = n_world
-    index_of, listings = {}, {}
-    for i, (o, chain, flip) in enumerate(leaves[:n_world]):
-        key = (id(o), chain, flip)
-        if isinstance(o, hit.ConstantMedium) and modes == {"hitlist"}:  # the k-th listing of this record (see _leaves)
-            k = listings.get(key, 0)
-            listings[key] = k + 1
-            key = key + (k,)
-        index_of[key] = i
-    fs.media_calls = np.array([index_of[k] for k in medium_calls], np.int32)
-    fs.media_mode = 1 if modes == {"hitlist"} else 0  # RTMI_MEDIA_HITLIST: the list's t-max narrowing reaches the media (rtmi_scene_set_media_mode)
+    index_of = {k: i for i, k in enumerate(keys)}
+    fs.media_calls = np.array([index_of[k] for k, lo in medium_calls], np.int32)
+    # per call: the first primitive of the Hitlist items that narrow it (= its own index: none) -- rtmi_scene_set_media_calls_narrowed
+    fs.media_narrow_from = np.array([index_of[k] if lo is None else lo for k, lo in medium_calls], np.int32)
+    # RTMI_MEDIA_HITLIST (1): the world is a Hitlist, its narrowing reaches every medium; 2 = RTMI_MEDIA_NARROWED: Hitlists holding media below bvh-nodes (round 4)
+    fs.media_mode = 1 if modes == {"hitlist"} else (2 if "narrowed" in modes or "hitlist" in modes else 0)
     n = len(leaves)
     fs.prim_kind = np.zeros(n, np.int32)
     fs.prim_geom = np.zeros((n, PRIM_STRIDE), np.float64)

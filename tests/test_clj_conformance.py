@@ -253,7 +253,7 @@ def test_gpu_clj_calls_conform_to_the_header():
         uses = {x[1] for x in walk(by_name[entry]) if is_list(x)}
         assert "create-scene!" in uses, "%s must build its scene through create-scene! (images, Perlin tables, media calls)" % entry
     helper = {f[2].strip('"') for f in walk(by_name["create-scene!"]) if is_list(f, "call-int")}
-    assert helper == {"rtmi_scene_create_ex", "rtmi_scene_set_perlin", "rtmi_scene_set_images", "rtmi_scene_set_media_calls", "rtmi_scene_set_media_mode"}
+    assert helper == {"rtmi_scene_create_ex", "rtmi_scene_set_perlin", "rtmi_scene_set_images", "rtmi_scene_set_media_calls", "rtmi_scene_set_media_mode", "rtmi_scene_set_media_calls_narrowed"}
 
 
 def test_integration_md_snippets_conform_to_the_header():

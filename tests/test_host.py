@@ -129,8 +129,15 @@ def test_flatten_media_modes():
     assert f.media_mode == 1 and list(f.media_calls) == [2] and f.n_prims == 4 and list(f.prim_kind[:4] & 15) == [0, 0, 7, 0]
     f = flatten.flatten({"camera": cam, "world": H.make_bvh([a, b, fog, c], 0.0, 1.0)})
     assert f.media_mode == 0 and len(f.media_calls) >= 1
-    with pytest.raises(flatten.UnsupportedOnGpuPath):
-        flatten.flatten({"camera": cam, "world": H.bvh_node(a, H.hitlist(items=[b, fog]), a.bbox(0.0, 1.0))})  # (the reference's Hitlist has no bbox: built by hand)
+    # a Hitlist holding a medium BELOW a bvh-node (rejected until round 3): narrowed per call -- by the items before it in its own list, not by the bvh siblings
+    f = flatten.flatten({"camera": cam, "world": H.bvh_node(a, H.hitlist(items=[b, fog, c]), a.bbox(0.0, 1.0))})  # (the reference's Hitlist has no bbox: built by hand)
+    assert f.media_mode == 2 and list(f.media_calls) == [2] and list(f.media_narrow_from) == [1] and list(f.prim_kind[:4] & 15) == [0, 0, 7, 0]
+    f = flatten.flatten({"camera": cam, "world": H.bvh_node(fog, H.hitlist(items=[b, H.hitlist(items=[c, fog])]), a.bbox(0.0, 1.0))})  # the same record: un-narrowed in the tree, narrowed in the (nested) list
+    assert f.media_mode == 2 and list(f.media_calls) == [0, 3] and list(f.media_narrow_from) == [0, 1]
+    with pytest.raises(flatten.UnsupportedOnGpuPath):  # a bvh-node INSIDE a Hitlist above the medium: narrowed by the list's earlier items but not by its bvh siblings
+        flatten.flatten({"camera": cam, "world": H.hitlist(items=[a, H.bvh_node(b, fog, a.bbox(0.0, 1.0))])})
+    with pytest.raises(flatten.UnsupportedOnGpuPath):  # the narrowing list shares a record with another part of the world: its items are not contiguous
+        flatten.flatten({"camera": cam, "world": H.bvh_node(a, H.hitlist(items=[a, fog]), a.bbox(0.0, 1.0))})
     # the same record listed twice in a Hitlist (rejected until round 3): every listing is a primitive of its own, at its own place
     f = flatten.flatten({"camera": cam, "world": H.hitlist(items=[a, fog, b, fog])})
     assert f.media_mode == 1 and list(f.media_calls) == [1, 3] and f.n_prims == 4 and list(f.prim_kind[:4] & 15) == [0, 7, 0, 7]
