@@ -307,3 +307,46 @@ def test_hitlists_holding_media_below_bvh_nodes_match_the_nested_oracle(oracle):
     bad = np.ascontiguousarray(c + 1, np.int32)
     assert r._ffi.lib().rtmi_scene_set_media_calls_narrowed(ds.handle, len(c), core.ptr(c), core.ptr(bad)) != 0  # narrow_from beyond the medium
     ds.close(); ctx.close()
+
+
+def test_tight_boxes_of_instanced_spheres_hold_on_silhouette_rays(monkeypatch):
+    """Round 4 bounds a sphere under Translate / RotateY wrappers by the box of the sphere about its MAPPED centre (centre +- r) instead of the box of its local box's
+    eight rotated corners.  The float traversal is only a filter in front of the exact test in the instance's frame, so the box must catch every ray that test
+    calls a hit: rays aimed at the silhouettes of make-final's thousand instanced spheres -- tangent within a few ulps inside and outside, from near and far,
+    along the axes and obliquely -- must give the tree the hits the flat scan gives, bit for bit."""
+    import math
+    flat = fl.flatten(r.scene.make_final(64, 64))
+    inst = np.flatnonzero((flat.prim_kind[:flat.n_prims] == fl.PRIM_SPHERE) & (flat.prim_xform[:flat.n_prims, 1] > 0))
+    assert len(inst) == 1000
+    rng = np.random.default_rng(21)
+    pick = rng.choice(inst, 6000)
+    first, count = flat.prim_xform[pick[0]]
+    assert count == 2 and np.all(flat.prim_xform[inst] == [first, count])
+    # outward map of the chain (innermost wrapper first): RotateY (sin, cos) then Translate
+    (k0, p0), (k1, p1) = [(int(flat.xform_kind[first + q]), flat.xform_param[first + q]) for q in range(2)]
+    assert k0 == fl.XFORM_TRANSLATE and k1 == fl.XFORM_ROTATE_Y
+    c = flat.prim_geom[pick, :3].copy()
+    sn, cs = p1[0], p1[1]
+    cw = np.stack([cs * c[:, 0] + sn * c[:, 2], c[:, 1], -sn * c[:, 0] + cs * c[:, 2]], axis=1) + p0[None, :]
+    rad = flat.prim_geom[pick, 3]
+    d = rng.normal(0, 1, (len(pick), 3))
+    d[::5] = np.eye(3)[rng.integers(0, 3, len(d[::5]))] * rng.choice([-1.0, 1.0], len(d[::5]))[:, None] + rng.normal(0, 1e-9, (len(d[::5]), 3))  # nearly axis-parallel
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    perp = np.cross(d, rng.normal(0, 1, d.shape))
+    perp /= np.linalg.norm(perp, axis=1)[:, None]
+    miss = rad * (1.0 + rng.choice([-1e-13, -1e-15, 0.0, 1e-15, 1e-13, 1e-9, -1e-9, 1e-6, -1e-6], len(pick)))   # tangent distance: inside / on / outside the silhouette
+    dist = rng.choice([0.5, 3.0, 30.0, 3000.0], len(pick))  # (the cluster is dense: only rays that start close to the tangent point meet their own sphere first)
+    o = cw + perp * miss[:, None] - d * dist[:, None]
+    rays = np.concatenate([o, d * rng.uniform(0.5, 2.0, (len(pick), 1)), rng.uniform(0, 1, (len(pick), 1))], axis=1)
+    monkeypatch.setenv("RTMI_FLAT_BELOW", "0")
+    ctx = core.default_context()
+    out = {}
+    for accel in (1, 0):
+        ctx.set_option("accel", accel)
+        ds = core.DeviceScene(flat)
+        out[accel] = ds.probe_hit(rays, 0.001, 3.4028234663852886e38)
+        ds.close()
+    ctx.set_option("accel", 1)
+    assert np.array_equal(out[0], out[1], equal_nan=True)
+    hit_target = (out[0][:, 0] > 0) & (out[0][:, 1] == pick)
+    assert 0.05 < hit_target.mean() < 0.6 and (out[0][:, 0] > 0).mean() > 0.9  # the rays do graze: a good share end on the very sphere they were aimed at, not all
