@@ -1159,6 +1159,7 @@ inline double box_area(const BvhBox &b) { const double x = b.hi[0] - b.lo[0], y 
 inline float f_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -INFINITY); return f; }
 inline float f_up(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, INFINITY); return f; }
 
+#include <unistd.h> // getpid (the team below must not be used by a forked child)
 // Host-side scene preparation (the device's trees) runs on a small TEAM of threads created once per process and kept: on the GPU boxes of this pool creating a
 // thread costs ~0.3 ms, a team of 16 per call cost more than the 11 025 rectangle trees it built.  run(fn): the caller and every worker execute fn() once.
 static std::atomic<int> g_build_single{0}; // test hook (rtmi_test_build_tree): build on the calling thread only
@@ -1176,6 +1177,7 @@ class WorkTeam {
     unsigned long gen = 0;
     unsigned pending = 0;
     bool stop = false;
+    pid_t owner;
     void loop() {
         unsigned long seen = 0;
         for (;;) {
@@ -1191,12 +1193,14 @@ class WorkTeam {
         }
     }
 public:
-    explicit WorkTeam(unsigned n) { for (unsigned t = 1; t < n; ++t) th.emplace_back([this] { loop(); }); }
+    explicit WorkTeam(unsigned n) : owner(getpid()) { for (unsigned t = 1; t < n; ++t) th.emplace_back([this] { loop(); }); }
     ~WorkTeam() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (std::thread &t : th) t.join(); }
-    static WorkTeam &get() { static WorkTeam team(team_size()); return team; }
+    // one team per process, never destroyed (its threads wait on the condition variable until the process exits: no join in a static destructor, which a host
+    // that unloads libraries in its own order -- a JVM, an interpreter -- could run while they still wait); a forked child has the object but not the threads
+    static WorkTeam &get() { static WorkTeam *team = new WorkTeam(team_size()); return *team; }
     void run(const std::function<void()> &f) {
         std::unique_lock<std::mutex> use(use_mu, std::try_to_lock);
-        if (!use.owns_lock() || th.empty() || g_build_single.load()) { f(); return; } // the team is busy with another host thread's scene: this one builds alone
+        if (!use.owns_lock() || th.empty() || g_build_single.load() || getpid() != owner) { f(); return; } // the team is busy with another host thread's scene: this one builds alone
         { std::lock_guard<std::mutex> lk(mu); fn = &f; pending = (unsigned)th.size(); ++gen; }
         cv.notify_all();
         f();
