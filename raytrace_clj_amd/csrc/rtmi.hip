@@ -134,15 +134,15 @@ __device__ inline void scan_cull_dispatch(SceneRef sc, const Path<float> &P, flo
 // hit? of the whole world for the lane's ray (closest hit, t in (t-min, t-max); core.clj:25 passes 0.001, Float/MAX_VALUE).
 // MULTI (LDS variants only): the static spheres do not fit one LDS tile; every thread of the workgroup must call this.
 // section 8(f3) scenes (FP64 only): BVH or culled flat scan over mixed primitive kinds with the any-order tie rule
-// MSEQ: the instantiations for RTMI_MEDIA_HITLIST worlds (their own kernels: the plain mixed-kind kernels keep their registers)
-template <bool SLICED = false, bool COUNT = false, bool MSEQ = false>
+// MSEQ: the instantiations for RTMI_MEDIA_HITLIST (1) and RTMI_MEDIA_NARROWED (2) worlds (their own kernels: the plain mixed-kind kernels keep their registers)
+template <bool SLICED = false, bool COUNT = false, int MSEQ = 0>
 __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<double> &P, bool active, double tmin, double tmax, double &best_t, int &best_i,
                                      bool *mid = nullptr, int min_lanes = 0, unsigned *cnt = nullptr, int susp_off = RTMI_BVH_STACK * RTMI_BVH_STRIDE) {
     best_t = tmax; best_i = -1;
     if (!active) return;
     const double a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
     ExtHit H = {tmax, 0x7fffffff, -1, false};
-    if (MSEQ && sc.media_seq == 2) {
+    if (MSEQ == 2) { // (an instantiation of its own: with both list forms inlined side by side one of the kernels went to 248 registers and scratch)
         // RTMI_MEDIA_NARROWED: Hitlists holding media BELOW bvh-nodes (round 4).  A bvh-node hands its children the un-narrowed interval (hitable.clj:99-105), a Hitlist
         // hands every item the closest hit of the items before it (hitable.clj:15-26): call k of the media sequence sees the closest hit among the primitives
         // [media_lo[k], media_idx[k]) -- the items before it in its own (possibly nested) Hitlist -- or the caller's t-max when that range is empty.  The items of one
@@ -168,7 +168,7 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
         if (best_i >= 0) best_t = H.t;
         return;
     }
-    if (MSEQ) {
+    if (MSEQ == 1) {
         // RTMI_MEDIA_HITLIST: the world is a Hitlist (hitable.clj:15-26: (hit? item r t-min closest-so-far), item after item).  Surfaces may be
         // folded in any order (ExtHit reproduces the list's tie rule), so the list is scanned in pieces: the surfaces before the first medium,
         // that medium with the t-max the list would hand it -- the closest hit so far --, the surfaces up to the next medium, and so on.  (These
@@ -211,12 +211,12 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
     best_i = ext_winner(H);
     if (best_i >= 0) best_t = H.t;
 }
-template <bool SLICED = false, bool COUNT = false, bool MSEQ = false>
+template <bool SLICED = false, bool COUNT = false, int MSEQ = 0>
 __device__ inline void intersect_ext(SceneRef, int *, bool, Path<float> &, bool, float, float tmax, float &best_t, int &best_i, bool * = nullptr, int = 0, unsigned * = nullptr, int = 0) { best_t = tmax; best_i = -1; }
 
 // NOGRID: the plain (not time-sliced) RENDER kernel -- never launched on a scene with an entry grid, so it carries no code for one (the probe
 // kernels, also not time-sliced, do: they walk a long segment's pieces in a loop of their own)
-template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICED = false, bool MSEQ = false, bool NOGRID = false>
+template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICED = false, int MSEQ = 0, bool NOGRID = false>
 __device__ inline void intersect_world(SceneRef sc, Prim4<R> *lds, int prims_per_tile, int n_ptiles, Path<R> &P,
                                        bool active, R tmin, R tmax, R &best_t, int &best_i, unsigned *cnt = nullptr, bool *mid = nullptr, int min_lanes = 0,
                                        int susp_off = RTMI_BVH_STACK * RTMI_BVH_STRIDE) {
@@ -283,10 +283,10 @@ template <typename R> __device__ inline void start_sample(SceneRef sc, const Tra
 
 // SLICE: time-sliced BVH traversal (section 5.1b of DESIGN.md); the plain instantiation is kept for scenes whose tree is too small to gain
 // LST: the sphere (non-EXT) time-sliced BVH kernel with the camera-ray stash in LDS and stack columns sized by the scene's tree (launch site: when it fits)
-template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICE = true, bool MSEQ = false, bool LST = false>
+template <typename R, bool MULTI, int VARIANT, bool EXT = false, bool COUNT = false, bool SLICE = true, int MSEQ = 0, bool LST = false>
 // (the Hitlist-with-media (MSEQ) and the counting (COUNT) instantiations of the mixed-kind kernels need more than the 128 VGPRs of four waves per SIMD: rather
 // than spill, they are compiled for three -- rare worlds and a diagnostic; the kernels the benchmarks run keep four)
-__global__ void __launch_bounds__(kTraceBlock, EXT ? ((MSEQ || COUNT) ? 3 : RTMI_EXT_MIN_WAVES) : RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
+__global__ void __launch_bounds__(kTraceBlock, EXT ? ((MSEQ != 0 || COUNT) ? 3 : RTMI_EXT_MIN_WAVES) : RTMI_MIN_WAVES) trace_kernel(ScenePtr scp, TraceParams tp) {
     SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Prim4<R> *lds = reinterpret_cast<Prim4<R> *>(smem);
@@ -623,7 +623,7 @@ template <typename R> __device__ inline void load_ray(const double *q, Path<R> &
     P.ar = P.ag = P.ab = R(1); seed_stream(P, 0ull, 0u); P.depth = 0;
 }
 
-template <typename R, int VARIANT, bool EXT = false, bool MSEQ = false>
+template <typename R, int VARIANT, bool EXT = false, int MSEQ = 0>
 __global__ void __launch_bounds__(kBlock) probe_hit_kernel(ScenePtr scp, int prims_per_tile, int n_ptiles, int n, const double *rays, double tmin, double tmax, double *out) {
     SceneRef sc = *scp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(kBlock) probe_hit_kernel(ScenePtr scp, int pri
     o[6] = h.nx; o[7] = h.ny; o[8] = h.nz; o[9] = h.u; o[10] = h.v;
 }
 
-template <typename R, int VARIANT, bool EXT = false, bool MSEQ = false>
+template <typename R, int VARIANT, bool EXT = false, int MSEQ = 0>
 __global__ void __launch_bounds__(kBlock) probe_paths_kernel(ScenePtr scp, int prims_per_tile, int n_ptiles, int n, const double *rays, const u64 *keys, u64 ctr0,
                                                              int depth, double *out_rgb, u64 *out_nseg, double *log, int max_seg, int *out_nlog) {
     SceneRef sc = *scp;
@@ -1034,10 +1034,12 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
             return (size_t)(levels + susp_words + stash_words) * kTraceBlock * sizeof(int);
         };
         if (s->dev.has_ext && s->dev.media_seq) { // a Hitlist world holding media (RTMI_MEDIA_HITLIST): its own instantiations, never time-sliced
+            const bool nar = s->dev.media_seq == 2; // RTMI_MEDIA_NARROWED: Hitlists holding media below bvh-nodes (MSEQ = 2)
             if (variant == SCAN_BVH) {
-                kern = c->count_traversal ? trace_kernel<double, false, SCAN_BVH, true, true, false, true> : trace_kernel<double, false, SCAN_BVH, true, false, false, true>;
+                if (nar) kern = c->count_traversal ? trace_kernel<double, false, SCAN_BVH, true, true, false, 2> : trace_kernel<double, false, SCAN_BVH, true, false, false, 2>;
+                else kern = c->count_traversal ? trace_kernel<double, false, SCAN_BVH, true, true, false, 1> : trace_kernel<double, false, SCAN_BVH, true, false, false, 1>;
                 dyn_lds = ext_lds(true, 0);
-            } else { kern = trace_kernel<double, false, SCAN_SGPR_CULL, true, false, true, true>; dyn_lds = ext_lds(false, 0); }
+            } else { kern = nar ? trace_kernel<double, false, SCAN_SGPR_CULL, true, false, true, 2> : trace_kernel<double, false, SCAN_SGPR_CULL, true, false, true, 1>; dyn_lds = ext_lds(false, 0); }
         } else if (s->dev.has_ext) { // section 8(f3) scenes: FP64 kernels with the mixed-kind intersectors
             if (variant == SCAN_BVH) { // a Cornell box's 20-primitive tree loses 5 % to the time-slicing machinery, make-final's 3400 gain 8 %
                 const bool slice = s->bvh_node_count >= 128 && tp.suspend_lanes > 0;
@@ -2220,6 +2222,11 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
                 const int bits = (t < 0 || t >= n_tex) ? 3 : uses[(size_t)t];
                 if (bits & 1) pk_dev[(size_t)i] |= RTMI_PRIM_NEEDS_U;
                 if (bits & 2) pk_dev[(size_t)i] |= RTMI_PRIM_NEEDS_V;
+            } else if (pk[(size_t)i] >= RTMI_PRIM_RECT_XY && pk[(size_t)i] <= RTMI_PRIM_TRIANGLE) {
+                // a rectangle's uv is two IEEE divisions per hit (hitable.clj:283-284), a triangle's a second Moeller-Trumbore: computed only where the material's
+                // texture reads uv at all (both coordinates then: no coordinate is ever replaced here, so nothing deviates) -- a Cornell box's walls never do
+                const int m = pm[(size_t)i], t = (m >= 0 && m < n_mats) ? mat_tex[m] : -1;
+                if (t < 0 || t >= n_tex || uses[(size_t)t]) pk_dev[(size_t)i] |= RTMI_PRIM_NEEDS_UV;
             }
         if (!rc) rc = upload(s, pk_dev, &d.prim_kind);
         std::vector<int> km((size_t)std::max(n_prims, 1) * 2, 0);
@@ -2877,9 +2884,9 @@ RTMI_EXPORT int rtmi_probe_hit(rtmi_scene *s, int32_t precision, int32_t n, cons
     if (precision == RTMI_F64) {
         lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
         if (s->dev.has_ext) {
-            const bool seq = s->dev.media_seq != 0;
-            if (c->accel == RTMI_ACCEL_BVH) hipLaunchKernelGGL((seq ? probe_hit_kernel<double, SCAN_BVH, true, true> : probe_hit_kernel<double, SCAN_BVH, true>), dim3(grid), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
-            else hipLaunchKernelGGL((seq ? probe_hit_kernel<double, SCAN_SGPR_CULL, true, true> : probe_hit_kernel<double, SCAN_SGPR_CULL, true>), dim3(grid), dim3(kBlock), 64, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
+            const int seq = s->dev.media_seq;
+            if (c->accel == RTMI_ACCEL_BVH) hipLaunchKernelGGL((seq == 2 ? probe_hit_kernel<double, SCAN_BVH, true, 2> : seq ? probe_hit_kernel<double, SCAN_BVH, true, 1> : probe_hit_kernel<double, SCAN_BVH, true>), dim3(grid), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
+            else hipLaunchKernelGGL((seq == 2 ? probe_hit_kernel<double, SCAN_SGPR_CULL, true, 2> : seq ? probe_hit_kernel<double, SCAN_SGPR_CULL, true, 1> : probe_hit_kernel<double, SCAN_SGPR_CULL, true>), dim3(grid), dim3(kBlock), 64, c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out);
         } else
         switch (c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant) {
         case SCAN_BVH: hipLaunchKernelGGL((probe_hit_kernel<double, SCAN_BVH>), dim3(grid), dim3(kBlock), std::max(lds, (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16), c->stream, s->d_dev, ppt, npt, n, d_rays, t_min, t_max, d_out); break;
@@ -2922,9 +2929,9 @@ RTMI_EXPORT int rtmi_probe_paths(rtmi_scene *s, int32_t precision, int32_t n, co
     if (precision == RTMI_F64) {
         lds_plan(c, s->dev.n_static, sizeof(double), &ppt, &npt, &lds);
         if (s->dev.has_ext) {
-            const bool seq = s->dev.media_seq != 0;
-            if (c->accel == RTMI_ACCEL_BVH) hipLaunchKernelGGL((seq ? probe_paths_kernel<double, SCAN_BVH, true, true> : probe_paths_kernel<double, SCAN_BVH, true>), dim3(grid), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
-            else hipLaunchKernelGGL((seq ? probe_paths_kernel<double, SCAN_SGPR_CULL, true, true> : probe_paths_kernel<double, SCAN_SGPR_CULL, true>), dim3(grid), dim3(kBlock), 64, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
+            const int seq = s->dev.media_seq;
+            if (c->accel == RTMI_ACCEL_BVH) hipLaunchKernelGGL((seq == 2 ? probe_paths_kernel<double, SCAN_BVH, true, 2> : seq ? probe_paths_kernel<double, SCAN_BVH, true, 1> : probe_paths_kernel<double, SCAN_BVH, true>), dim3(grid), dim3(kBlock), (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
+            else hipLaunchKernelGGL((seq == 2 ? probe_paths_kernel<double, SCAN_SGPR_CULL, true, 2> : seq ? probe_paths_kernel<double, SCAN_SGPR_CULL, true, 1> : probe_paths_kernel<double, SCAN_SGPR_CULL, true>), dim3(grid), dim3(kBlock), 64, c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog);
         } else
         switch (c->accel == RTMI_ACCEL_BVH ? SCAN_BVH : c->scan_variant) {
         case SCAN_BVH: hipLaunchKernelGGL((probe_paths_kernel<double, SCAN_BVH>), dim3(grid), dim3(kBlock), std::max(lds, (size_t)RTMI_BVH_STACK * kBlock * sizeof(int) + 16), c->stream, s->d_dev, ppt, npt, n, d_rays, d_keys, (u64)ctr0, depth, d_rgb, d_nseg, d_log, max_seg, d_nlog); break;

@@ -1887,7 +1887,8 @@ template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path
 // the hit record of an f3 primitive: the innermost record's {:t :p :uv :normal} in ITS frame, then every wrapper's
 // outward step in reverse order -- RotateY post-rotates p and the normal (hitable.clj:441-446), Translate adds its offset
 // to p (hitable.clj:396), FlipNormals negates the normal (hitable.clj:380; negation commutes exactly with the rotation)
-__device__ inline void resolve_hit_ext(SceneRef sc, const Path<double> &P, double t, int orig, HitRec<double> &h) {
+// all_uv = false (the render): a rectangle's / triangle's uv only where the hit material's texture reads it (device copy of prim_kind: RTMI_PRIM_NEEDS_UV)
+__device__ inline void resolve_hit_ext(SceneRef sc, const Path<double> &P, double t, int orig, HitRec<double> &h, bool all_uv = true) {
     const int4 info = reinterpret_cast<const int4 *>(sc.ext_info)[orig];
     const LocalRay r = ext_local_ray(sc, info.z, info.w, P);
     const double *g = sc.exact12 + (size_t)orig * 12;
@@ -1906,7 +1907,7 @@ __device__ inline void resolve_hit_ext(SceneRef sc, const Path<double> &P, doubl
         nx = px - cx; ny = py - cy; nz = pz - cz;
         const double len = rt_sqrt(dot3(nx, ny, nz, nx, ny, nz));
         if (len > 0.0) { const double inv = 1.0 / len; nx = nx * inv; ny = ny * inv; nz = nz * inv; }
-        if (kind == RTMI_PRIM_UVSPHERE) {
+        if (kind == RTMI_PRIM_UVSPHERE && (all_uv || (sc.prim_kind[orig] & RTMI_PRIM_NEEDS_UV))) { // (both coordinates whenever the texture reads either: nothing is replaced on this path)
             Real<double>::sphere_uv(nx, ny, nz, &h.u, &h.v);
         }
     } else if (kind == RTMI_PRIM_MEDIUM) { // hitable.clj:536-540: uv [0 0] and normal (1,0,0) are arbitrary
@@ -1914,13 +1915,17 @@ __device__ inline void resolve_hit_ext(SceneRef sc, const Path<double> &P, doubl
     } else if (kind <= RTMI_PRIM_RECT_YZ) {
         int ax, ua, va;
         rect_axes(kind, ax, ua, va);
-        const double x = pick3(ua, r.ox, r.oy, r.oz) + t * pick3(ua, r.dx, r.dy, r.dz), y = pick3(va, r.ox, r.oy, r.oz) + t * pick3(va, r.dx, r.dy, r.dz);
-        h.u = (x - g[0]) / (g[2] - g[0]); h.v = (y - g[1]) / (g[3] - g[1]);
+        if (all_uv || (sc.prim_kind[orig] & RTMI_PRIM_NEEDS_UV)) {
+            const double x = pick3(ua, r.ox, r.oy, r.oz) + t * pick3(ua, r.dx, r.dy, r.dz), y = pick3(va, r.ox, r.oy, r.oz) + t * pick3(va, r.dx, r.dy, r.dz);
+            h.u = (x - g[0]) / (g[2] - g[0]); h.v = (y - g[1]) / (g[3] - g[1]);
+        }
         nx = ax == 0 ? 1.0 : 0.0; ny = ax == 1 ? 1.0 : 0.0; nz = ax == 2 ? 1.0 : 0.0;
     } else {
-        double u = 0.0, v = 0.0, tt;
-        tri_mt(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], r, u, v, tt);
-        h.u = u; h.v = v;
+        if (all_uv || (sc.prim_kind[orig] & RTMI_PRIM_NEEDS_UV)) {
+            double u = 0.0, v = 0.0, tt;
+            tri_mt(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], r, u, v, tt);
+            h.u = u; h.v = v;
+        }
         cross3(g[3] - g[0], g[4] - g[1], g[5] - g[2], g[6] - g[0], g[7] - g[1], g[8] - g[2], nx, ny, nz); // not normalised (hitable.clj:570)
     }
     if (info.y) { nx = -nx; ny = -ny; nz = -nz; }
@@ -1937,7 +1942,7 @@ __device__ inline void resolve_hit_ext(SceneRef sc, const Path<double> &P, doubl
     h.px = px; h.py = py; h.pz = pz; h.nx = nx; h.ny = ny; h.nz = nz;
 }
 template <typename R, bool EXT> __device__ inline void resolve_any(SceneRef sc, const Path<R> &P, R t, int orig, HitRec<R> &h, bool all_uv = true) { resolve_hit<R>(sc, P, t, orig, h, all_uv); }
-template <> __device__ inline void resolve_any<double, true>(SceneRef sc, const Path<double> &P, double t, int orig, HitRec<double> &h, bool) { resolve_hit_ext(sc, P, t, orig, h); }
+template <> __device__ inline void resolve_any<double, true>(SceneRef sc, const Path<double> &P, double t, int orig, HitRec<double> &h, bool all_uv) { resolve_hit_ext(sc, P, t, orig, h, all_uv); }
 
 // Shader.scatter + Shader.emitted for the hit record, and the atten/accum update of core.clj:27-39.
 // Returns true when the path continues (the `recur` of core.clj:30) with P holding the scattered ray.
