@@ -52,9 +52,9 @@ constexpr int kTraceBlock = RTMI_TRACE_BLOCK; // threads per workgroup of the tr
 __device__ unsigned long long g_wg_t[2][4096]; // s_memrealtime (100 MHz) at workgroup start / end
 __device__ inline unsigned long long real_now() { unsigned long long t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }
 #define RTMI_STAMP_DECL const unsigned long long st_wg0 = real_now(); \
-    if (lane == 0) for (int k_ = 0; k_ < 50; ++k_) g_ph[threadIdx.x >> 6][k_] = 0; \
+    if (lane == 0) for (int k_ = 0; k_ < 3 * PH_SLOTS + 2; ++k_) g_ph[threadIdx.x >> 6][k_] = 0; \
     ph_stamp(-1); for (int k_ = 0; k_ < 32; ++k_) ph_stamp(PH_CAL);
-#define RTMI_STAMP_FLUSH(cnt) if (lane == 0) for (int k_ = 0; k_ < 48; ++k_) if (g_ph[threadIdx.x >> 6][k_]) atomicAdd(&g_phase[k_], g_ph[threadIdx.x >> 6][k_]); \
+#define RTMI_STAMP_FLUSH(cnt) if (lane == 0) for (int k_ = 0; k_ < 3 * PH_SLOTS; ++k_) if (g_ph[threadIdx.x >> 6][k_]) atomicAdd(&g_phase[k_], g_ph[threadIdx.x >> 6][k_]); \
     __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4096) { g_wg_t[0][blockIdx.x] = st_wg0; g_wg_t[1][blockIdx.x] = real_now(); }
 #else
 #define RTMI_STAMP_DECL
@@ -149,7 +149,7 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
         // Hitlist are contiguous in the flattened order, so the narrowing state is a running closest hit over that list: its surfaces are scanned piece by piece
         // between its media (index-restricted scan: such lists are short), every medium's candidate joins it.  The world's closest hit is then the fold of ALL
         // surfaces (one traversal, below) and of the media's candidates -- in any order (ExtHit).
-        MediumChord chord; chord.idx = -1; chord.ok = false; chord.t1 = chord.t2 = chord.mag = 0.0;
+        MediumChord chord = medium_chord_begin(P);
         ExtHit Hrun = {tmax, 0x7fffffff, -1, false};
         int cur_lo = -1, scanned_to = 0;
         for (int k = 0; k < sc.n_media; ++k) {
@@ -174,7 +174,7 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
         // that medium with the t-max the list would hand it -- the closest hit so far --, the surfaces up to the next medium, and so on.  (These
         // scenes run the instantiation without time-slicing: media_seq and SLICED never meet.)
         int prev = 0;
-        MediumChord chord; chord.idx = -1; chord.ok = false; chord.t1 = chord.t2 = chord.mag = 0.0;
+        MediumChord chord = medium_chord_begin(P);
         for (int k = 0; k <= sc.n_media; ++k) {
             const int m = k < sc.n_media ? sc.media_idx[k] : sc.n_all;
             if (m > prev) {
@@ -195,9 +195,9 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
     // walks the tree with an unbounded interval before its medium is asked.  The reference's call order is kept: primitive-index order = the order its descent
     // calls the media (and draws).  A resumed lane (time-sliced traversal) evaluated its media when its segment began; they ride in its parked hit state.
     if (!(SLICED && bvh && *mid)) {
-        MediumChord chord; chord.idx = -1; chord.ok = false; chord.t1 = chord.t2 = chord.mag = 0.0;
+        MediumChord chord = medium_chord_begin(P);
         for (int k = 0; k < sc.n_media; ++k) ext_medium_test(sc, sc.media_idx[k], P, tmin, tmax, H, chord, COUNT ? cnt : nullptr);
-        RTMI_PH(PH_LOOP) // (diagnostic build: the media are booked on the otherwise unused first phase)
+        RTMI_PH(PH_MEDIA)
     }
     if (bvh) {
         if (SLICED) {
@@ -1108,7 +1108,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
     {
         const int grid_trace_dbg = c->last_grid;
         HIP_TRY(hipStreamSynchronize(st));
-        unsigned long long h[48] = {0}, z[48] = {0};
+        unsigned long long h[3 * PH_SLOTS] = {0}, z[3 * PH_SLOTS] = {0};
         HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)));
         {
@@ -1123,15 +1123,16 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         }
         static const char *names[PH_N] = {"loop/tail", "refill: generate 64 camera rays", "refill: claim + deal", "bvh: ray setup / resume", "bvh: big primitives (exact)",
                                           "bvh: descent (node visits)", "bvh: leaf exact tests", "bvh: loop control / park", "shade: hit record", "shade: |d| normalise",
-                                          "shade: rand-in-unit-sphere", "shade: material record + directions", "shade: texture", "shade: store / rest", "shade: sphere uv", "(stamp calibration)"};
+                                          "shade: rand-in-unit-sphere", "shade: material record + directions", "shade: texture", "shade: store / rest", "shade: sphere uv", "(stamp calibration)",
+                                          "bvh: grid entry / next piece of the walk", "media: chords, draws, log"};
         // every interval begins with the bookkeeping of the stamp that opened it: subtract the cost of one stamp (PH_CAL: back-to-back stamps) per stamp
-        const double per_stamp = h[32 + PH_CAL] ? (double)h[PH_CAL] / (double)h[32 + PH_CAL] : 0.0;
+        const double per_stamp = h[2 * PH_SLOTS + PH_CAL] ? (double)h[PH_CAL] / (double)h[2 * PH_SLOTS + PH_CAL] : 0.0;
         double tk[PH_N], lk[PH_N], tot = 0, totl = 0, raw = 0;
         for (int k = 0; k < PH_N; ++k) {
             raw += (double)h[k];
-            const double t = (double)h[k], c = std::min(t, per_stamp * (double)h[32 + k]);
+            const double t = (double)h[k], c = std::min(t, per_stamp * (double)h[2 * PH_SLOTS + k]);
             tk[k] = k == PH_CAL ? 0.0 : t - c;
-            lk[k] = t > 0 ? (double)h[16 + k] * (tk[k] / t) : 0.0;
+            lk[k] = t > 0 ? (double)h[PH_SLOTS + k] * (tk[k] / t) : 0.0;
             tot += tk[k]; totl += lk[k];
         }
         fprintf(stderr, "[phases] one stamp = %.0f ticks; stamps took %.1f %% of the %.4g wave-ticks of this (diagnostic) launch and are subtracted below\n", per_stamp, 100 * (raw - tot) / raw, raw);
@@ -1139,7 +1140,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         for (int k = 0; k < PH_N; ++k) {
             if (!h[k] || k == PH_CAL) continue;
             const double t = tk[k], l = lk[k];
-            fprintf(stderr, "[phases] %-36s %8.2f %8.1f %10.2f %10.2f %12llu\n", names[k], 100 * t / tot, t > 0 ? l / t : 0.0, 100 * (64 * t - l) / (64 * tot), 100 * l / (64 * tot), h[32 + k]);
+            fprintf(stderr, "[phases] %-36s %8.2f %8.1f %10.2f %10.2f %12llu\n", names[k], 100 * t / tot, t > 0 ? l / t : 0.0, 100 * (64 * t - l) / (64 * tot), 100 * l / (64 * tot), h[2 * PH_SLOTS + k]);
         }
         fprintf(stderr, "[phases] %-36s %8.2f %8.1f %10.2f %10.2f   (%.4g wave-ticks)\n", "total", 100.0, totl / tot, 100 * (64 * tot - totl) / (64 * tot), 100 * totl / (64 * tot), tot);
     }

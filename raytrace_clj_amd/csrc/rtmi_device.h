@@ -124,8 +124,9 @@ __host__ __device__ inline u64 draw_bits(u64 key, u64 d) { return mix64(key + RT
 // cycles) and as lane-ticks = ticks x the lanes active AT the stamp.  A stamp therefore sits at the END of the code it names, inside
 // the divergent region if that code runs under a lane mask (a region no lane enters executes no stamp: its few scalar cycles fall to
 // the next stamp).  Accumulators live in LDS, one row per wave, updated by the wave's first active lane; flushed once per launch.
-enum { PH_LOOP = 0, PH_REFILL_GEN, PH_REFILL_DEAL, PH_BVH_SETUP, PH_BIG, PH_DESCENT, PH_LEAF, PH_BVH_POST, PH_HITREC, PH_DNORM, PH_SAMPLER, PH_DIRS, PH_TEXTURE, PH_STORE, PH_UV, PH_CAL, PH_N }; // PH_CAL: back-to-back stamps = the cost of a stamp, subtracted per stamp on the host
-__shared__ unsigned long long g_ph[4][3 * 16 + 2]; // [wave]: ticks[16], lane-ticks[16], stamps[16], last stamp, unused
+enum { PH_LOOP = 0, PH_REFILL_GEN, PH_REFILL_DEAL, PH_BVH_SETUP, PH_BIG, PH_DESCENT, PH_LEAF, PH_BVH_POST, PH_HITREC, PH_DNORM, PH_SAMPLER, PH_DIRS, PH_TEXTURE, PH_STORE, PH_UV, PH_CAL, PH_GRID, PH_MEDIA, PH_N }; // PH_CAL: back-to-back stamps = the cost of a stamp, subtracted per stamp on the host
+#define PH_SLOTS 20
+__shared__ unsigned long long g_ph[4][3 * PH_SLOTS + 2]; // [wave]: ticks[PH_SLOTS], lane-ticks[PH_SLOTS], stamps[PH_SLOTS], last stamp, unused
 __device__ inline void ph_stamp(int k, unsigned lane_trips = 0, unsigned trips = 0) { // trips > 0: book lane_trips / trips lanes per tick instead of the stamp's own mask (loops that count their lanes per trip)
     __builtin_amdgcn_sched_barrier(0);
     unsigned long long t;
@@ -133,13 +134,13 @@ __device__ inline void ph_stamp(int k, unsigned lane_trips = 0, unsigned trips =
     const unsigned long long ex = __ballot(1);
     const int w = threadIdx.x >> 6;
     if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
-        const unsigned long long dt = t - g_ph[w][48];
+        const unsigned long long dt = t - g_ph[w][3 * PH_SLOTS];
         if (k >= 0) {
-            g_ph[w][32 + k] += 1;
+            g_ph[w][2 * PH_SLOTS + k] += 1;
             g_ph[w][k] += dt;
-            g_ph[w][16 + k] += trips ? dt * (unsigned long long)lane_trips / (unsigned long long)trips : dt * (unsigned long long)__popcll(ex);
+            g_ph[w][PH_SLOTS + k] += trips ? dt * (unsigned long long)lane_trips / (unsigned long long)trips : dt * (unsigned long long)__popcll(ex);
         }
-        g_ph[w][48] = t;
+        g_ph[w][3 * PH_SLOTS] = t;
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -1006,7 +1007,7 @@ __device__ inline BvhRay make_bvh_ray(SceneRef sc, const Path<R> &P, R a, R tmin
 // column per thread (stack[level * blockDim.x + tid]: conflict-free).  leaf(code) runs the exact test, best() returns the
 // current float upper bound of the closest t.
 #ifdef RTMI_STAMPS // diagnostic build only (make stamps)
-__device__ unsigned long long g_phase[48]; // [0..15] wave ticks per phase, [16..31] lane-ticks, [32..47] stamps executed, summed over the launch's waves
+__device__ unsigned long long g_phase[3 * PH_SLOTS]; // [0..PH_SLOTS) wave ticks per phase, then lane-ticks, then stamps executed, summed over the launch's waves
 #endif
 // Where a lane's traversal stands: node = the node to visit next (inner node: byte offset of its record (>= 0); leaf: ~(primitive |
 // moving << 30) (< 0); RTMI_BVH_EMPTY: done), tos = the newest stack entry (a register), top = next free slot of the thread's LDS column.
@@ -1282,7 +1283,10 @@ __device__ inline bool scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, 
     bool enter = CHUNK && sc.grid_n && (!(SLICE && resume) || reenter), first = !reenter;
     for (;;) {
         if (enter) // where the traversal starts: the roots of the grid cells the ray's segment (or its next piece) crosses, or the root of the whole tree
+        {
             t_split = bvh_grid_entry(sc, r, (float)P.ox, (float)P.oy, (float)P.oz, (float)P.dx, (float)P.dy, (float)P.dz, best(), e_rel, cur, t_from, first);
+            RTMI_PH(PH_GRID)
+        }
         bvh_traverse<COUNT, SLICE>(sc, r, cur, min_lanes, leaf, best, cnt);
         if (SLICE && cur.node != RTMI_BVH_EMPTY) { // suspended
             int w0, w1;
@@ -1586,12 +1590,34 @@ __device__ inline void scan_small_ext(SceneRef sc, const Path<double> &P, double
 // The boundary part is a function of (medium, ray) alone -- no draw, no t-min / t-max --, so a medium the reference asks twice in a row (make-bvh stores a lone
 // item as bvh-node(L, L) and hit? evaluates both children, hitable.clj:113-114: make-final's haze is media call 2 AND 3 of every ray) computes it once:
 // MediumChord caches it for the next call with the same index (the index sequence is wave-uniform).
-struct MediumChord { int idx; bool ok; double t1, t2, mag; };
+// The divisions of a medium's hit? -- two boundary roots by a = d.d, -(log xi) by the density, the hit distance by |d| (hitable.clj:183-207, 529-537) -- take the
+// refined-reciprocal form (RefinedRcp: the IEEE sequence's own last three operations, the same bits while the division would not rescale its operands: checked per
+// lane, numerator and divisor; anything else divides).  For a medium without an instance chain a, |d| and their reciprocals are the RAY's: medium_chord_begin
+// evaluates them once per segment for all media calls (make-final: three calls, two media; 12 divisions and 2 square roots per segment before).
+struct MediumChord { int idx; bool ok; double t1, t2, mag, rmag, rden; double ray_a, ray_ra, ray_mag, ray_rmag; };
+__device__ inline bool num_in_range(double n) { return ((unsigned)__double2hiint(n) & 0x7fffffffu) - (54u << 20) < (1537u << 20); } // 2^-969 <= |n| < 2^568
+__device__ inline MediumChord medium_chord_begin(const Path<double> &P) {
+    MediumChord C;
+    C.idx = -1; C.ok = false; C.t1 = C.t2 = C.mag = C.rmag = C.rden = 0.0;
+    C.ray_a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
+    C.ray_ra = refined_rcp(C.ray_a).r;
+    C.ray_mag = rt_sqrt(C.ray_a);
+    C.ray_rmag = refined_rcp(C.ray_mag).r;
+    return C;
+}
 __device__ inline void ext_medium_chord(SceneRef sc, int idx, const Path<double> &P, MediumChord &C, unsigned *cnt = nullptr) {
     const double FMAX = 3.4028234663852886e38;
     const size_t gi = (size_t)idx * 12; // idx comes from media_idx: wave-uniform
     const int first = (int)ext_ld<true>(sc.exact12, gi + 1), count = (int)ext_ld<true>(sc.exact12, gi + 2);
-    C.idx = idx; C.ok = false; C.t1 = C.t2 = C.mag = 0.0;
+    C.idx = idx; C.ok = false; C.t1 = C.t2 = C.mag = C.rmag = 0.0;
+    C.rden = refined_rcp(ext_ld<true>(sc.exact12, gi)).r;
+    const int4 info = ext_ld_info<true>(sc.ext_info, idx);
+    auto own_mag = [&]() { // |d| of the ray as the medium sees it (its own chain; none: the ray's)
+        if (info.w == 0) { C.mag = C.ray_mag; C.rmag = C.ray_rmag; return; }
+        const LocalRay rm = ext_local_ray<true>(sc, info.z, info.w, P);
+        C.mag = rt_sqrt(dot3(rm.dx, rm.dy, rm.dz, rm.dx, rm.dy, rm.dz));
+        C.rmag = refined_rcp(C.mag).r;
+    };
     if (count == 1) { // (wave-uniform) a boundary that is ONE plain sphere -- make-final's two media, make-subsurface-sphere --: both closest-hit scans evaluate the same
         // quadratic (hitable.clj:183-207), so it is evaluated once: the scan over the whole line takes the first root, the scan from first root + 0.0001 the second
         // (the first cannot exceed itself + 0.0001).  The same operations on the same operands as the two generic scans below; anything unusual (a root that is
@@ -1603,21 +1629,25 @@ __device__ inline void ext_medium_chord(SceneRef sc, int idx, const Path<double>
             Prim4<double> s;
             s.cx = ext_ld<true>(sc.exact12, bi); s.cy = ext_ld<true>(sc.exact12, bi + 1); s.cz = ext_ld<true>(sc.exact12, bi + 2); s.r2 = ext_ld<true>(sc.exact12, bi + 3);
             Path<double> L; L.ox = r.ox; L.oy = r.oy; L.oz = r.oz; L.dx = r.dx; L.dy = r.dy; L.dz = r.dz;
-            const double a = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
+            RefinedRcp qa;
+            if (binfo.w == 0) { qa.a = C.ray_a; qa.r = C.ray_ra; } // (wave-uniform) the boundary stands in the world's frame: r is the ray itself
+            else qa = refined_rcp(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
+            const double a = qa.a;
+            const bool fa = rcp_in_range(a);
             double bq, cq, disc;
             sphere_test(s, L, a, bq, cq, disc);
             if (!(disc >= 0.0)) { if (cnt) cnt[1] += 1u; return; } // the line misses the boundary: no first hit
             const double sq = rt_sqrt(disc);
-            const double tA = (-bq - sq) / a;
+            const double nA = -bq - sq;
+            const double tA = div_by(nA, qa, fa && num_in_range(nA));
             const double tmin2 = tA + 0.0001;
             if (tA > -FMAX && tA < FMAX && !(tA > tmin2)) { // the first scan's hit, and not the second scan's (else, i.e. never for finite roots: the generic scans)
                 if (cnt) cnt[1] += 2u;
                 if (tmin2 >= 0.0 && bq > 0.0 && cq > 0.0) return; // ext_prim_test's exact early-out of the second scan: both roots <= 0
-                const double tB = (-bq + sq) / a;
+                const double nB = -bq + sq;
+                const double tB = div_by(nB, qa, fa && num_in_range(nB));
                 if (!(tB > tmin2 && tB < FMAX)) return; // the second scan finds nothing
-                const int4 info = ext_ld_info<true>(sc.ext_info, idx);
-                const LocalRay rm = ext_local_ray<true>(sc, info.z, info.w, P);
-                C.mag = rt_sqrt(dot3(rm.dx, rm.dy, rm.dz, rm.dx, rm.dy, rm.dz));
+                own_mag();
                 C.t1 = tA; C.t2 = tB; C.ok = true;
                 return;
             }
@@ -1631,9 +1661,7 @@ __device__ inline void ext_medium_chord(SceneRef sc, int idx, const Path<double>
     ExtHit h2 = {FMAX, 0x7fffffff, -1, false};
     for (int k = 0; k < count; ++k) ext_prim_test<true>(sc, first + k, P, h1.t + 0.0001, h2);
     if (!h2.any) return;
-    const int4 info = ext_ld_info<true>(sc.ext_info, idx);
-    const LocalRay r = ext_local_ray<true>(sc, info.z, info.w, P);
-    C.mag = rt_sqrt(dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz));
+    own_mag();
     C.t1 = h1.t; C.t2 = h2.t; C.ok = true;
 }
 // hit_t (optional): receives the medium's hit parameter when it hits (the return value says whether)
@@ -1645,11 +1673,12 @@ __device__ inline bool ext_medium_test(SceneRef sc, int idx, Path<double> &P, do
     if (t2 > tmax) t2 = tmax;
     if (!(t1 < t2)) return false;
     if (t1 < 0.0) t1 = 0.0;
-    const double density = ext_ld<true>(sc.exact12, (size_t)idx * 12);
+    const RefinedRcp qd = {ext_ld<true>(sc.exact12, (size_t)idx * 12), C.rden}, qm = {C.mag, C.rmag};
     const double dist_in = (t2 - t1) * C.mag;
-    const double hit_distance = -(rt_log_unit(next_uniform(P)) / density);
+    const double lg = rt_log_unit(next_uniform(P));
+    const double hit_distance = -div_by(lg, qd, rcp_in_range(qd.a) && num_in_range(lg));
     if (!(hit_distance < dist_in)) return false;
-    const double t = t1 + hit_distance / C.mag;
+    const double t = t1 + div_by(hit_distance, qm, rcp_in_range(qm.a) && num_in_range(hit_distance));
     ext_update(H, t, idx, true);
     if (hit_t) *hit_t = t;
     return true;

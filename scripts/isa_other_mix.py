@@ -76,7 +76,8 @@ if len(sys.argv) > 3 and sys.argv[1] == "--phases":
     names = {"loop/tail": "PH_LOOP", "refill: generate 64 camera rays": "PH_REFILL_GEN", "refill: claim + deal": "PH_REFILL_DEAL", "bvh: ray setup / resume": "PH_BVH_SETUP",
              "bvh: big primitives (exact)": "PH_BIG", "bvh: descent (node visits)": "PH_DESCENT", "bvh: leaf exact tests": "PH_LEAF", "bvh: loop control / park": "PH_BVH_POST",
              "shade: hit record": "PH_HITREC", "shade: |d| normalise": "PH_DNORM", "shade: rand-in-unit-sphere": "PH_SAMPLER", "shade: material record + directions": "PH_DIRS",
-             "shade: texture": "PH_TEXTURE", "shade: store / rest": "PH_STORE", "shade: sphere uv": "PH_UV"}
+             "shade: texture": "PH_TEXTURE", "shade: store / rest": "PH_STORE", "shade: sphere uv": "PH_UV",
+             "bvh: grid entry / next piece of the walk": "PH_GRID", "media: chords, draws, log": "PH_MEDIA"}
     weight, on = {}, False
     for l in open(table):
         if l.startswith("== "):
