@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PHASES = len(sys.argv) > 1 and sys.argv[1] == "--phases"
 path = sys.argv[2] if PHASES else (sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "build", "rtmi-hip-amdgcn-amd-amdhsa-gfx950.s"))
-pat = (sys.argv[2] if len(sys.argv) > 2 and not PHASES else "_ZN12_GLOBAL__N_112trace_kernelIdLb0ELi4ELb0ELb0ELb1ELb0ELb1E")  # <double, false, BVH, false, false, SLICE, false, LST>: the C3 kernel
+pat = (sys.argv[2] if len(sys.argv) > 2 and not PHASES else "_ZN12_GLOBAL__N_112trace_kernelIdLb0ELi4ELb0ELb0ELb1ELi0ELb1E")  # <double, false, BVH, false, false, SLICE, 0, LST>: the C3 kernel
 lines, on = [], False
 for l in open(path):
     if l.startswith(pat):
