@@ -1324,11 +1324,18 @@ __device__ inline bool scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, 
 // the first tied primitive, else the first.  F = lowest tied index, W = highest tied inclusive index: winner = max(F, W).
 struct ExtHit { double t; int F, W; bool any; };
 __device__ inline int ext_winner(const ExtHit &H) { return H.any ? max(H.F, H.W) : -1; }
-__device__ inline void ext_update(ExtHit &H, double t, int idx, bool incl) {
-    if (!H.any) { // H.t is the caller's t-max
-        if (incl ? (t <= H.t) : (t < H.t)) { H.t = t; H.F = idx; H.W = incl ? idx : -1; H.any = true; }
-    } else if (t < H.t) { H.t = t; H.F = idx; H.W = incl ? idx : -1; }
-    else if (t == H.t) { H.F = min(H.F, idx); if (incl) H.W = max(H.W, idx); }
+// Branch-free (selects under lane masks): as nested `if`s the candidate tests of a mixed-kind scan compiled to three to five levels of divergent control flow per
+// primitive, each level with copies of the whole state at its join (a rectangle test: 13 arithmetic instructions among ~40 moves and ~45 scalar mask operations).
+// ok = false: the candidate is no hit at all (t outside the interval, the point outside the rectangle): nothing changes.
+__device__ inline void ext_update(ExtHit &H, double t, int idx, bool incl, bool ok = true) {
+    const bool clt = t < H.t, ceq = t == H.t; // (H.t is the caller's t-max until the first hit)
+    const bool take = ok & (clt | (incl & ceq & !H.any));
+    const bool tie = ok & ceq & H.any;
+    const int F1 = tie ? min(H.F, idx) : H.F, W1 = (tie & incl) ? max(H.W, idx) : H.W;
+    H.F = take ? idx : F1;
+    H.W = take ? (incl ? idx : -1) : W1;
+    H.t = take ? t : H.t;
+    H.any = H.any | take;
 }
 
 struct LocalRay { double ox, oy, oz, dx, dy, dz; };
@@ -1427,10 +1434,8 @@ __device__ inline double div_by(double n, const RefinedRcp &d, bool fast) {
 __device__ inline void box_face(double k, double oa, const RefinedRcp &da, bool fast, double ou, double du, double ov, double dv, double u0, double u1, double v0, double v1,
                                 double tmin, int idx, ExtHit &H) {
     const double t = div_by(k - oa, da, fast);
-    if (t >= tmin) {
-        const double x = ou + t * du, y = ov + t * dv;
-        if (x >= u0 && x <= u1 && y >= v0 && y <= v1) ext_update(H, t, idx, true);
-    }
+    const double x = ou + t * du, y = ov + t * dv; // (for every lane: a t below t-min or not a number fails the first comparison)
+    ext_update(H, t, idx, true, (t >= tmin) & (x >= u0) & (x <= u1) & (y >= v0) & (y <= v1));
 }
 // r: the ray in the box's frame (ext_local_ray of the six rectangles' common chain); rec: the first rectangle's record (x0 y0 x1 y1 z1 z0)
 __device__ inline void ext_box_faces(const LocalRay &r, double x0, double y0, double x1, double y1, double z1, double z0, double tmin, int idx, ExtHit &H) {
@@ -1483,17 +1488,15 @@ __device__ inline void ext_prim_test_local(SceneRef sc, int idx, int kind, const
             const double sq = rt_sqrt(disc);
             double t = (-bq - sq) / a;
             if (!(t > tmin)) t = (-bq + sq) / a;
-            if (t > tmin) ext_update(H, t, idx, false);
+            ext_update(H, t, idx, false, t > tmin);
         }
     } else if (kind <= RTMI_PRIM_RECT_YZ) {
         const double gk = ext_ld<UNIFORM>(sc.exact12, gi + 4);
         // the rectangle's plane axis a and its two in-plane axes u, v
         auto rect = [&](double oa, double da, double ou, double du, double ov, double dv) {
             const double t = (gk - oa) / da;
-            if (t >= tmin) {
-                const double x = ou + t * du, y = ov + t * dv;
-                if (x >= g0 && x <= g2 && y >= g1 && y <= g3) ext_update(H, t, idx, true);
-            }
+            const double x = ou + t * du, y = ov + t * dv;
+            ext_update(H, t, idx, true, (t >= tmin) & (x >= g0) & (x <= g2) & (y >= g1) & (y <= g3));
         };
         if (UNIFORM) { // scalar branches on the kind, one copy of the test per kind: no selects, no indexed temporaries
             if (q) { // g = (u0 v0 u1 v1)
@@ -1513,7 +1516,7 @@ __device__ inline void ext_prim_test_local(SceneRef sc, int idx, int kind, const
     } else {
         double u, v, t;
         if (tri_mt(g0, g1, g2, g3, ext_ld<UNIFORM>(sc.exact12, gi + 4), ext_ld<UNIFORM>(sc.exact12, gi + 5), ext_ld<UNIFORM>(sc.exact12, gi + 6),
-                   ext_ld<UNIFORM>(sc.exact12, gi + 7), ext_ld<UNIFORM>(sc.exact12, gi + 8), r, u, v, t) && t >= tmin) ext_update(H, t, idx, true);
+                   ext_ld<UNIFORM>(sc.exact12, gi + 7), ext_ld<UNIFORM>(sc.exact12, gi + 8), r, u, v, t)) ext_update(H, t, idx, true, t >= tmin);
     }
 }
 // hit? of primitive idx (any kind, through its instance chain) folded into the any-order state
@@ -1727,17 +1730,15 @@ __device__ inline void ext_leaf_test(SceneRef sc, int idx, bool box, const Path<
             const double sq = rt_sqrt(disc);
             double t = (-bq - sq) / a;
             if (!(t > tmin)) t = (-bq + sq) / a;
-            if (t > tmin) ext_update(H, t, idx, false);
+            ext_update(H, t, idx, false, t > tmin);
         }
     } else { // a rectangle: plane axis a, in-plane axes u, v
         int ax, ua, va;
         rect_axes(kind, ax, ua, va);
         const double oa = pick3(ax, r.ox, r.oy, r.oz), da = pick3(ax, r.dx, r.dy, r.dz);
         const double t = (g4 - oa) / da;
-        if (t >= tmin) {
-            const double x = pick3(ua, r.ox, r.oy, r.oz) + t * pick3(ua, r.dx, r.dy, r.dz), y = pick3(va, r.ox, r.oy, r.oz) + t * pick3(va, r.dx, r.dy, r.dz);
-            if (x >= g0 && x <= g2 && y >= g1 && y <= g3) ext_update(H, t, idx, true);
-        }
+        const double x = pick3(ua, r.ox, r.oy, r.oz) + t * pick3(ua, r.dx, r.dy, r.dz), y = pick3(va, r.ox, r.oy, r.oz) + t * pick3(va, r.dx, r.dy, r.dz);
+        ext_update(H, t, idx, true, (t >= tmin) & (x >= g0) & (x <= g2) & (y >= g1) & (y <= g3));
     }
 }
 
