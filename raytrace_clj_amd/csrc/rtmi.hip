@@ -141,7 +141,7 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
     best_t = tmax; best_i = -1;
     if (!active) return;
     const double a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
-    ExtHit H = {tmax, 0x7fffffff, -1, false};
+    ExtHit H = {tmax, 0x7fffffff, -1};
     if (MSEQ == 2) { // (an instantiation of its own: with both list forms inlined side by side one of the kernels went to 248 registers and scratch)
         // RTMI_MEDIA_NARROWED: Hitlists holding media BELOW bvh-nodes (round 4).  A bvh-node hands its children the un-narrowed interval (hitable.clj:99-105), a Hitlist
         // hands every item the closest hit of the items before it (hitable.clj:15-26): call k of the media sequence sees the closest hit among the primitives
@@ -150,15 +150,15 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
         // between its media (index-restricted scan: such lists are short), every medium's candidate joins it.  The world's closest hit is then the fold of ALL
         // surfaces (one traversal, below) and of the media's candidates -- in any order (ExtHit).
         MediumChord chord = medium_chord_begin(P);
-        ExtHit Hrun = {tmax, 0x7fffffff, -1, false};
+        ExtHit Hrun = {tmax, 0x7fffffff, -1};
         int cur_lo = -1, scanned_to = 0;
         for (int k = 0; k < sc.n_media; ++k) {
             const int m = sc.media_idx[k], lo = sc.media_lo[k];
             if (lo >= m) { ext_medium_test(sc, m, P, tmin, tmax, H, chord, COUNT ? cnt : nullptr); continue; } // un-narrowed: a medium reached through bvh-nodes only
-            if (lo != cur_lo) { Hrun.t = tmax; Hrun.F = 0x7fffffff; Hrun.W = -1; Hrun.any = false; cur_lo = lo; scanned_to = lo; }
+            if (lo != cur_lo) { Hrun.t = tmax; Hrun.F = 0x7fffffff; Hrun.W = -1; cur_lo = lo; scanned_to = lo; }
             if (m > scanned_to) scan_all_cull_ext(sc, P, a, tmin, Hrun, scanned_to, m);
             double tm = 0.0;
-            if (ext_medium_test(sc, m, P, tmin, Hrun.any ? Hrun.t : tmax, Hrun, chord, COUNT ? cnt : nullptr, &tm)) ext_update(H, tm, m, true);
+            if (ext_medium_test(sc, m, P, tmin, Hrun.any() ? Hrun.t : tmax, Hrun, chord, COUNT ? cnt : nullptr, &tm)) ext_update(H, tm, m, true);
             scanned_to = m + 1;
         }
         if (bvh) scan_bvh_ext<false, COUNT>(sc, stack, P, a, tmin, H, nullptr, false, 0, cnt);
@@ -182,7 +182,7 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
                 else if (sc.small_scan) scan_small_ext(sc, P, tmin, H, prev, m);
                 else scan_all_cull_ext(sc, P, a, tmin, H, prev, m);
             }
-            if (k < sc.n_media) ext_medium_test(sc, m, P, tmin, H.any ? H.t : tmax, H, chord, COUNT ? cnt : nullptr);
+            if (k < sc.n_media) ext_medium_test(sc, m, P, tmin, H.any() ? H.t : tmax, H, chord, COUNT ? cnt : nullptr);
             prev = m + 1;
         }
         best_i = ext_winner(H);

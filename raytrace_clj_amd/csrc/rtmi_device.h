@@ -1322,20 +1322,20 @@ __device__ inline bool scan_bvh(SceneRef sc, int *stack, const Path<R> &P, R a, 
 // so far) a sphere replaces the current hit only if t < closest (hitable.clj:195) while rectangles and triangles use
 // t <= closest (hitable.clj:278, 564): among primitives tied at the minimal t the winner is the LAST "inclusive" one after
 // the first tied primitive, else the first.  F = lowest tied index, W = highest tied inclusive index: winner = max(F, W).
-struct ExtHit { double t; int F, W; bool any; };
-__device__ inline int ext_winner(const ExtHit &H) { return H.any ? max(H.F, H.W) : -1; }
+struct ExtHit { double t; int F, W; __device__ inline bool any() const { return F != 0x7fffffff; } }; // F = 0x7fffffff: no hit yet, t = the caller's t-max
+__device__ inline int ext_winner(const ExtHit &H) { return H.any() ? max(H.F, H.W) : -1; }
 // Branch-free (selects under lane masks): as nested `if`s the candidate tests of a mixed-kind scan compiled to three to five levels of divergent control flow per
 // primitive, each level with copies of the whole state at its join (a rectangle test: 13 arithmetic instructions among ~40 moves and ~45 scalar mask operations).
 // ok = false: the candidate is no hit at all (t outside the interval, the point outside the rectangle): nothing changes.
 __device__ inline void ext_update(ExtHit &H, double t, int idx, bool incl, bool ok = true) {
     const bool clt = t < H.t, ceq = t == H.t; // (H.t is the caller's t-max until the first hit)
-    const bool take = ok & (clt | (incl & ceq & !H.any));
-    const bool tie = ok & ceq & H.any;
+    const bool any = H.any();
+    const bool take = ok & (clt | (incl & ceq & !any));
+    const bool tie = ok & ceq & any;
     const int F1 = tie ? min(H.F, idx) : H.F, W1 = (tie & incl) ? max(H.W, idx) : H.W;
     H.F = take ? idx : F1;
     H.W = take ? (incl ? idx : -1) : W1;
     H.t = take ? t : H.t;
-    H.any = H.any | take;
 }
 
 struct LocalRay { double ox, oy, oz, dx, dy, dz; };
@@ -1431,9 +1431,12 @@ __device__ inline double div_by(double n, const RefinedRcp &d, bool fast) {
     return ::fma(::fma(-d.a, q, n), d.r, q);
 }
 // one face: the rectangle in the plane x_a = k, in-plane coordinates (u, v) within [u0, u1] x [v0, v1]
+// fast_all (wave-uniform): every lane of the wave is `fast` -- one scalar branch instead of a lane mask around the plain division
 __device__ inline void box_face(double k, double oa, const RefinedRcp &da, bool fast, double ou, double du, double ov, double dv, double u0, double u1, double v0, double v1,
-                                double tmin, int idx, ExtHit &H) {
-    const double t = div_by(k - oa, da, fast);
+                                double tmin, int idx, ExtHit &H, bool fast_all = false) {
+    double t;
+    if (fast_all) { const double n = k - oa, q = n * da.r; t = ::fma(::fma(-da.a, q, n), da.r, q); }
+    else t = div_by(k - oa, da, fast);
     const double x = ou + t * du, y = ov + t * dv; // (for every lane: a t below t-min or not a number fails the first comparison)
     ext_update(H, t, idx, true, (t >= tmin) & (x >= u0) & (x <= u1) & (y >= v0) & (y <= v1));
 }
@@ -1467,7 +1470,8 @@ __device__ inline void ext_box_test(SceneRef sc, int idx, const Path<double> &P,
 // q (optional): the refined reciprocals of r's direction components (ext_box_faces) -- a rectangle's t = (k - o_a) / d_a then costs the division's last
 // three operations (`fast`, per lane: see RefinedRcp); nullptr: the plain division.
 template <bool UNIFORM = false>
-__device__ inline void ext_prim_test_local(SceneRef sc, int idx, int kind, const LocalRay &r, double time, double tmin, ExtHit &H, const RefinedRcp *q = nullptr, bool fast = false) {
+__device__ inline void ext_prim_test_local(SceneRef sc, int idx, int kind, const LocalRay &r, double time, double tmin, ExtHit &H, const RefinedRcp *q = nullptr, bool fast = false,
+                                           bool fast_all = false) {
     const size_t gi = (size_t)idx * 12;
     const double g0 = ext_ld<UNIFORM>(sc.exact12, gi), g1 = ext_ld<UNIFORM>(sc.exact12, gi + 1), g2 = ext_ld<UNIFORM>(sc.exact12, gi + 2),
                  g3 = ext_ld<UNIFORM>(sc.exact12, gi + 3);
@@ -1500,9 +1504,9 @@ __device__ inline void ext_prim_test_local(SceneRef sc, int idx, int kind, const
         };
         if (UNIFORM) { // scalar branches on the kind, one copy of the test per kind: no selects, no indexed temporaries
             if (q) { // g = (u0 v0 u1 v1)
-                if (kind == RTMI_PRIM_RECT_XY) box_face(gk, r.oz, q[2], fast, r.ox, r.dx, r.oy, r.dy, g0, g2, g1, g3, tmin, idx, H);
-                else if (kind == RTMI_PRIM_RECT_XZ) box_face(gk, r.oy, q[1], fast, r.ox, r.dx, r.oz, r.dz, g0, g2, g1, g3, tmin, idx, H);
-                else box_face(gk, r.ox, q[0], fast, r.oy, r.dy, r.oz, r.dz, g0, g2, g1, g3, tmin, idx, H);
+                if (kind == RTMI_PRIM_RECT_XY) box_face(gk, r.oz, q[2], fast, r.ox, r.dx, r.oy, r.dy, g0, g2, g1, g3, tmin, idx, H, fast_all);
+                else if (kind == RTMI_PRIM_RECT_XZ) box_face(gk, r.oy, q[1], fast, r.ox, r.dx, r.oz, r.dz, g0, g2, g1, g3, tmin, idx, H, fast_all);
+                else box_face(gk, r.ox, q[0], fast, r.oy, r.dy, r.oz, r.dz, g0, g2, g1, g3, tmin, idx, H, fast_all);
             }
             else if (kind == RTMI_PRIM_RECT_XY) rect(r.oz, r.dz, r.ox, r.dx, r.oy, r.dy);
             else if (kind == RTMI_PRIM_RECT_XZ) rect(r.oy, r.dy, r.ox, r.dx, r.oz, r.dz);
@@ -1554,7 +1558,7 @@ __device__ inline void scan_small_ext(SceneRef sc, const Path<double> &P, double
     int cf = -1, cc = -1; // the chain the cached local ray belongs to
     LocalRay lr = {P.ox, P.oy, P.oz, P.dx, P.dy, P.dz};
     RefinedRcp q[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
-    bool fast = false;
+    bool fast = false, fast_all = false;
     int i = max(lo, 0);
     if (i >= n) return;
 #if RTMI_SMALL_SCAN_PREFETCH
@@ -1573,6 +1577,7 @@ __device__ inline void scan_small_ext(SceneRef sc, const Path<double> &P, double
             lr = ext_local_ray<true>(sc, cf, cc, P);
             q[0] = refined_rcp(lr.dx); q[1] = refined_rcp(lr.dy); q[2] = refined_rcp(lr.dz);
             fast = rcp_in_range(lr.dx) && rcp_in_range(lr.dy) && rcp_in_range(lr.dz) && tmin >= 0x1p-300 && H.t <= 0x1p200;
+            fast_all = __all(fast) != 0;
         }
 #if RTMI_SMALL_SCAN_PREFETCH
         if (info.x >= RTMI_PRIM_RECT_XY && info.x <= RTMI_PRIM_RECT_YZ) { // a rectangle: its record is already here
@@ -1582,7 +1587,7 @@ __device__ inline void scan_small_ext(SceneRef sc, const Path<double> &P, double
             continue;
         }
 #endif
-        ext_prim_test_local<true>(sc, i, info.x, lr, P.time, tmin, H, q, fast);
+        ext_prim_test_local<true>(sc, i, info.x, lr, P.time, tmin, H, q, fast, fast_all);
     }
 }
 
@@ -1656,14 +1661,14 @@ __device__ inline void ext_medium_chord(SceneRef sc, int idx, const Path<double>
             }
         }
     }
-    ExtHit h1 = {FMAX, 0x7fffffff, -1, false};
+    ExtHit h1 = {FMAX, 0x7fffffff, -1};
     for (int k = 0; k < count; ++k) ext_prim_test<true>(sc, first + k, P, -FMAX, h1); // idx (a medium of media_idx) is wave-uniform
     if (cnt) cnt[1] += (unsigned)count; // exact tests of the boundary's primitives
-    if (!h1.any) return;
+    if (!h1.any()) return;
     if (cnt) cnt[1] += (unsigned)count;
-    ExtHit h2 = {FMAX, 0x7fffffff, -1, false};
+    ExtHit h2 = {FMAX, 0x7fffffff, -1};
     for (int k = 0; k < count; ++k) ext_prim_test<true>(sc, first + k, P, h1.t + 0.0001, h2);
-    if (!h2.any) return;
+    if (!h2.any()) return;
     own_mag();
     C.t1 = h1.t; C.t2 = h2.t; C.ok = true;
 }
@@ -1765,7 +1770,7 @@ __device__ inline float ext_best_hi(const ExtHit &H) { return float_above(H.t); 
 
 // Time-sliced like scan_bvh (susp: RTMI_BVH_SUSPEND_WORDS_EXT columns behind the stack; returns false when the lane's traversal was
 // suspended): the mixed-kind scenes need it most -- make-final's descent trips ran at 12.7 of 64 lanes, 66 % of them below 8.
-#define RTMI_BVH_SUSPEND_WORDS_EXT 7 // node, tos, top, H.t (2 words), H.F, H.W   (H.any <=> H.F != 0x7fffffff)
+#define RTMI_BVH_SUSPEND_WORDS_EXT 7 // node, tos, top, H.t (2 words), H.F, H.W   (no hit yet <=> H.F = 0x7fffffff)
 template <bool SLICE = false, bool COUNT = false>
 __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> &P, double a, double tmin, ExtHit &H, int *susp = nullptr, bool resume = false,
                                     int min_lanes = 0, unsigned *cnt = nullptr, int lo = 0, int hi = 0x7fffffff) {
@@ -1777,7 +1782,7 @@ __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> 
         cur.node = sw[0]; cur.tos = sw[stride];
         cur.top = reinterpret_cast<int *>(reinterpret_cast<char *>(stack) + sw[2 * stride]);
         H.t = __hiloint2double(sw[4 * stride], sw[3 * stride]);
-        H.F = sw[5 * stride]; H.W = sw[6 * stride]; H.any = H.F != 0x7fffffff;
+        H.F = sw[5 * stride]; H.W = sw[6 * stride];
     } else {
         if (!r.ok) { if (COUNT) cnt[1] += (unsigned)sc.n_all; scan_all_cull_ext(sc, P, a, tmin, H, lo, hi); return true; }
         RTMI_PH(PH_BVH_SETUP)
@@ -1815,7 +1820,7 @@ __device__ inline bool scan_bvh_ext(SceneRef sc, int *stack, const Path<double> 
         sw[0] = cur.node; sw[stride] = cur.tos;
         sw[2 * stride] = (int)(reinterpret_cast<char *>(cur.top) - reinterpret_cast<char *>(stack));
         sw[3 * stride] = __double2loint(H.t); sw[4 * stride] = __double2hiint(H.t);
-        sw[5 * stride] = H.any ? H.F : 0x7fffffff; sw[6 * stride] = H.W;
+        sw[5 * stride] = H.F; sw[6 * stride] = H.W;
         return false;
     }
     if (!r.time_ok) { // e.g. after Isotropic.scatter, which sets the ray's time to the hit's t (shader.clj:136)
