@@ -2161,7 +2161,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
             double *q = &leaf_rec[(size_t)i * RTMI_LEAF_REC_DOUBLES];
             const int kind = pk[(size_t)i];
             const int xf_first = prim_xform ? prim_xform[2 * i] : 0, xf_count = prim_xform ? prim_xform[2 * i + 1] : 0;
-            int hdr[4] = {kind, 0, 0, 0};
+            int hdr[4] = {kind | ((prim_flip && (prim_flip[i] & 1)) ? 0x100 : 0), 0, 0, 0}; // bit 8: FlipNormals parity (resolve_hit_ext)
             const bool simple = (kind == RTMI_PRIM_SPHERE || kind == RTMI_PRIM_UVSPHERE || (kind >= RTMI_PRIM_RECT_XY && kind <= RTMI_PRIM_RECT_YZ)) && xf_count <= 2;
             if (!simple) hdr[1] = 1; // generic: ext_prim_test
             else {

@@ -1685,11 +1685,11 @@ __device__ inline bool ext_medium_test(SceneRef sc, int idx, Path<double> &P, do
     const double dist_in = (t2 - t1) * C.mag;
     const double lg = rt_log_unit(next_uniform(P));
     const double hit_distance = -div_by(lg, qd, rcp_in_range(qd.a) && num_in_range(lg));
-    if (!(hit_distance < dist_in)) return false;
-    const double t = t1 + div_by(hit_distance, qm, rcp_in_range(qm.a) && num_in_range(hit_distance));
-    ext_update(H, t, idx, true);
+    const bool hit = hit_distance < dist_in;
+    const double t = t1 + div_by(hit_distance, qm, rcp_in_range(qm.a) && num_in_range(hit_distance)); // (for every lane that drew; folded under `hit`: no branch, no state copies)
+    ext_update(H, t, idx, true, hit);
     if (hit_t) *hit_t = t;
-    return true;
+    return hit;
 }
 
 // ---- a tree leaf's exact test from ONE record ------------------------------------------------------------------------------------------------
@@ -1723,7 +1723,7 @@ __device__ inline void ext_leaf_test(SceneRef sc, int idx, bool box, const Path<
     }
     const double g0 = q1.x, g1 = q1.y, g2 = q2.x, g3 = q2.y, g4 = q3.x;
     if (box) { ext_box_faces(r, g0, g1, g2, g3, g4, q6.y, tmin, idx, H); return; }
-    const int kind = hdr.x;
+    const int kind = hdr.x & 0xff; // (bit 8: the FlipNormals parity, read by resolve_hit_ext)
     if (kind <= RTMI_PRIM_UVSPHERE) {
         Prim4<double> s;
         s.cx = g0; s.cy = g1; s.cz = g2; s.r2 = g3;
@@ -1923,7 +1923,59 @@ template <typename R> __device__ inline void resolve_hit(SceneRef sc, const Path
 // outward step in reverse order -- RotateY post-rotates p and the normal (hitable.clj:441-446), Translate adds its offset
 // to p (hitable.clj:396), FlipNormals negates the normal (hitable.clj:380; negation commutes exactly with the rotation)
 // all_uv = false (the render): a rectangle's / triangle's uv only where the hit material's texture reads it (device copy of prim_kind: RTMI_PRIM_NEEDS_UV)
+// the outward step of one wrapper (see below): Translate adds its offset to p, RotateY post-rotates p and the normal; a, b, c = the leaf record's parameters
+__device__ inline void leaf_xform_back(int xk, double a, double b, double c, double &px, double &py, double &pz, double &nx, double &nz) {
+    if (xk == 1) { px = px + a; py = py + b; pz = pz + c; }
+    else if (xk == 2) { // a = sin, b = cos
+        const double rx = b * px + a * pz, rz = (-(a * px)) + b * pz;
+        const double mx = b * nx + a * nz, mz = (-(a * nx)) + b * nz;
+        px = rx; pz = rz; nx = mx; nz = mz;
+    }
+}
 __device__ inline void resolve_hit_ext(SceneRef sc, const Path<double> &P, double t, int orig, HitRec<double> &h, bool all_uv = true) {
+#if RTMI_LEAF_RECORDS
+    { // The winner's LEAF RECORD (ext_leaf_test) holds what the common kinds need -- kind, flip parity, up to two wrappers with their parameters, the geometry -- at ONE
+      // address known from the index: seven loads issued together, where the generic path below reads the primitive's info, then walks its chain (a dependent
+      // load per wrapper, twice: inwards for the local ray, outwards for p and the normal), then reads the geometry.  The same operations on the same operands.
+        const double2 *q = reinterpret_cast<const double2 *>(sc.leaf_rec + (size_t)orig * RTMI_LEAF_REC_DOUBLES);
+        const int4 hdr = *reinterpret_cast<const int4 *>(q);
+        if (!hdr.y) {
+            const double2 q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+            const int kind = hdr.x & 0xff;
+            h.orig = orig; h.kind = kind; h.mat = sc.prim_mat[orig]; h.t = t;
+            const bool want_uv = all_uv || (sc.prim_kind[orig] & RTMI_PRIM_NEEDS_UV);
+            LocalRay r = {P.ox, P.oy, P.oz, P.dx, P.dy, P.dz};
+            if (hdr.z | hdr.w) {
+                leaf_xform(hdr.z, q3.y, q4.x, q4.y, r);
+                leaf_xform(hdr.w, q5.x, q5.y, q6.x, r);
+            }
+            double px = r.dx * t + r.ox, py = r.dy * t + r.oy, pz = r.dz * t + r.oz;
+            double nx, ny, nz;
+            h.u = 0.0; h.v = 0.0;
+            if (kind <= RTMI_PRIM_UVSPHERE) {
+                nx = px - q1.x; ny = py - q1.y; nz = pz - q2.x;
+                const double len = rt_sqrt(dot3(nx, ny, nz, nx, ny, nz));
+                if (len > 0.0) { const double inv = 1.0 / len; nx = nx * inv; ny = ny * inv; nz = nz * inv; }
+                if (kind == RTMI_PRIM_UVSPHERE && want_uv) Real<double>::sphere_uv(nx, ny, nz, &h.u, &h.v);
+            } else { // a rectangle: u0 v0 u1 v1 k
+                int ax, ua, va;
+                rect_axes(kind, ax, ua, va);
+                if (want_uv) {
+                    const double x = pick3(ua, r.ox, r.oy, r.oz) + t * pick3(ua, r.dx, r.dy, r.dz), y = pick3(va, r.ox, r.oy, r.oz) + t * pick3(va, r.dx, r.dy, r.dz);
+                    h.u = (x - q1.x) / (q2.x - q1.x); h.v = (y - q1.y) / (q2.y - q1.y);
+                }
+                nx = ax == 0 ? 1.0 : 0.0; ny = ax == 1 ? 1.0 : 0.0; nz = ax == 2 ? 1.0 : 0.0;
+            }
+            if (hdr.x & 0x100) { nx = -nx; ny = -ny; nz = -nz; }
+            if (hdr.z | hdr.w) {
+                leaf_xform_back(hdr.w, q5.x, q5.y, q6.x, px, py, pz, nx, nz);
+                leaf_xform_back(hdr.z, q3.y, q4.x, q4.y, px, py, pz, nx, nz);
+            }
+            h.px = px; h.py = py; h.pz = pz; h.nx = nx; h.ny = ny; h.nz = nz;
+            return;
+        }
+    }
+#endif
     const int4 info = reinterpret_cast<const int4 *>(sc.ext_info)[orig];
     const LocalRay r = ext_local_ray(sc, info.z, info.w, P);
     const double *g = sc.exact12 + (size_t)orig * 12;
