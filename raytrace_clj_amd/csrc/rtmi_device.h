@@ -1569,7 +1569,8 @@ __device__ inline void scan_small_ext(SceneRef sc, const Path<double> &P, double
         const int4 info = rec.info;
 #else
     for (; i < n; ++i) {
-        const int4 info = ext_ld_info<true>(sc.ext_info, i);
+        const SmallRec rec = small_rec(sc, i); // info and the first five geometry slots (a rectangle's whole record) requested together: one wait per primitive, not two
+        const int4 info = rec.info;
 #endif
         if (info.x == RTMI_PRIM_MEDIUM) continue;
         if (info.z != cf || info.w != cc) { // (wave-uniform)
@@ -1579,14 +1580,12 @@ __device__ inline void scan_small_ext(SceneRef sc, const Path<double> &P, double
             fast = rcp_in_range(lr.dx) && rcp_in_range(lr.dy) && rcp_in_range(lr.dz) && tmin >= 0x1p-300 && H.t <= 0x1p200;
             fast_all = __all(fast) != 0;
         }
-#if RTMI_SMALL_SCAN_PREFETCH
         if (info.x >= RTMI_PRIM_RECT_XY && info.x <= RTMI_PRIM_RECT_YZ) { // a rectangle: its record is already here
-            if (info.x == RTMI_PRIM_RECT_XY) box_face(rec.g4, lr.oz, q[2], fast, lr.ox, lr.dx, lr.oy, lr.dy, rec.g0, rec.g2, rec.g1, rec.g3, tmin, i, H);
-            else if (info.x == RTMI_PRIM_RECT_XZ) box_face(rec.g4, lr.oy, q[1], fast, lr.ox, lr.dx, lr.oz, lr.dz, rec.g0, rec.g2, rec.g1, rec.g3, tmin, i, H);
-            else box_face(rec.g4, lr.ox, q[0], fast, lr.oy, lr.dy, lr.oz, lr.dz, rec.g0, rec.g2, rec.g1, rec.g3, tmin, i, H);
+            if (info.x == RTMI_PRIM_RECT_XY) box_face(rec.g4, lr.oz, q[2], fast, lr.ox, lr.dx, lr.oy, lr.dy, rec.g0, rec.g2, rec.g1, rec.g3, tmin, i, H, fast_all);
+            else if (info.x == RTMI_PRIM_RECT_XZ) box_face(rec.g4, lr.oy, q[1], fast, lr.ox, lr.dx, lr.oz, lr.dz, rec.g0, rec.g2, rec.g1, rec.g3, tmin, i, H, fast_all);
+            else box_face(rec.g4, lr.ox, q[0], fast, lr.oy, lr.dy, lr.oz, lr.dz, rec.g0, rec.g2, rec.g1, rec.g3, tmin, i, H, fast_all);
             continue;
         }
-#endif
         ext_prim_test_local<true>(sc, i, info.x, lr, P.time, tmin, H, q, fast, fast_all);
     }
 }
