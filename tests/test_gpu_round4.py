@@ -350,3 +350,61 @@ def test_tight_boxes_of_instanced_spheres_hold_on_silhouette_rays(monkeypatch):
     assert np.array_equal(out[0], out[1], equal_nan=True)
     hit_target = (out[0][:, 0] > 0) & (out[0][:, 1] == pick)
     assert 0.05 < hit_target.mean() < 0.6 and (out[0][:, 0] > 0).mean() > 0.9  # the rays do graze: a good share end on the very sphere they were aimed at, not all
+
+
+def test_mixed_kind_ties_fold_like_the_hitlist(oracle):
+    """The branch-free fold of candidates into the closest-hit state (ext_update) against Hitlist.hit? (hitable.clj:15-26) where candidates TIE: a sphere
+    replaces the closest hit only if t < closest (hitable.clj:195), a rectangle if t <= closest (hitable.clj:278) -- among primitives tied at the minimal t the
+    last inclusive one after the first tied primitive wins, else the first.  The ray (0,0,0) -> (0,0,-1) meets the unit sphere about (0,0,-2) and the
+    rectangle z = -1 at t = 1 exactly; every order of spheres and rectangles, through the small-world scan, the culled scan and the tree, and with
+    t-max = 1 exactly (a rectangle at the caller's t-max is a hit, a sphere is not)."""
+    from oracle.tree import flatten_with_tree
+    import itertools
+    H, S, T = r.hitable, r.shader, r.texture
+    vec3 = lambda *a: np.array(a, np.float64)
+    cam = r.camera.pinhole_camera(lookfrom=vec3(0, 0, 0), lookat=vec3(0, 0, -1), vup=vec3(0, 1, 0), vfov=40, aspect=1.0)
+    def mat(k):
+        return S.lambertian(albedo=T.constant(color=vec3(0.1 * (k + 1), 0.5, 0.5)))
+    def sphere(k):
+        return H.sphere(center=vec3(0, 0, -2), radius=1.0, material=mat(k))
+    def rect(k):
+        return H.rect_xy(x0=-1, y0=-1, x1=1, y1=1, k=-1.0, material=mat(k))
+    far = [H.sphere(center=vec3(40 + 3 * k, 0, -50), radius=1.0, material=mat(9)) for k in range(3)]  # bystanders: the worlds are not all ties
+    rays = np.array([[0, 0, 0, 0, 0, -1, 0.0], [0, 0, 0, 0, 0, -2, 0.0], [0.25, -0.5, 0, 0, 0, -1, 0.0], [0, 0, 0, 0.1, 0, -1, 0.0]])
+    n_checked = 0
+    for pattern in itertools.product("sr", repeat=4):
+        items = [sphere(k) if c == "s" else rect(k) for k, c in enumerate(pattern)] + far
+        for world in (H.hitlist(items=items), H.make_bvh(items, 0.0, 1.0)):
+            f = flatten_with_tree({"camera": cam, "world": world})
+            for tmax in (3.4028234663852886e38, 1.0, 0.5):
+                exp = oracle.probe_hit(f, rays, tmax=tmax)
+                ctx = core.Context(0)
+                ds = core.DeviceScene(f, ctx=ctx)
+                got = {}
+                for tag, opts in (("small", {"accel": 0}), ("tree", {"accel": 1, "flat_below": 0})):
+                    for k, v in opts.items():
+                        ctx.set_option(k, v)
+                    got[tag] = ds.probe_hit(rays, t_max=tmax)
+                ds.close(); ctx.close()
+                os.environ["RTMI_SMALL_SCAN"] = "0"
+                try:
+                    ctx = core.Context(0)
+                    ds = core.DeviceScene(f, ctx=ctx)
+                    ctx.set_option("accel", 0)
+                    got["culled"] = ds.probe_hit(rays, t_max=tmax)
+                    ds.close(); ctx.close()
+                finally:
+                    del os.environ["RTMI_SMALL_SCAN"]
+                assert np.array_equal(got["small"], got["tree"]) and np.array_equal(got["small"], got["culled"]), (pattern, tmax)
+                if isinstance(world, H.Hitlist):  # (among bvh-node siblings the reference lets the RIGHT child win a tie, hitable.clj:103-105; the device folds a
+                    assert np.array_equal(got["small"][:, :9], exp[:, :9]), (pattern, tmax)  # flattened world by the Hitlist rule: exact ties between leaves are the one place they differ, DESIGN.md 5.1c)
+                # the rule itself, for the ray along the axis (every candidate ties at t = 1): the last rectangle if there is one, else the first sphere
+                if isinstance(world, H.Hitlist):
+                    first = got["small"][0]
+                    last_rect = max([k for k, c in enumerate(pattern) if c == "r"], default=-1)
+                    if tmax >= 1.0 and (last_rect >= 0 or tmax > 1.0):
+                        assert first[0] == 1.0 and first[2] == 1.0 and int(first[1]) == (last_rect if last_rect >= 0 else 0), (pattern, tmax, first[:3])
+                    else:
+                        assert first[0] == 0.0, (pattern, tmax, first[:3])
+                n_checked += 1
+    assert n_checked == 16 * 2 * 3
