@@ -1331,11 +1331,14 @@ __device__ inline void ext_update(ExtHit &H, double t, int idx, bool incl, bool 
     const bool clt = t < H.t, ceq = t == H.t; // (H.t is the caller's t-max until the first hit)
     const bool any = H.any();
     const bool take = ok & (clt | (incl & ceq & !any));
-    const bool tie = ok & ceq & any;
-    const int F1 = tie ? min(H.F, idx) : H.F, W1 = (tie & incl) ? max(H.W, idx) : H.W;
-    H.F = take ? idx : F1;
-    H.W = take ? (incl ? idx : -1) : W1;
+    const bool tie = ok & ceq & any; // (never together with `take`)
+    H.F = take ? idx : H.F;
+    H.W = take ? (incl ? idx : -1) : H.W;
     H.t = take ? t : H.t;
+    if (__builtin_expect(__any(tie), 0)) { // an exact tie in some lane of the wave: one scalar test in front of five vector instructions that almost never have work
+        H.F = tie ? min(H.F, idx) : H.F;
+        if (incl) H.W = tie ? max(H.W, idx) : H.W;
+    }
 }
 
 struct LocalRay { double ox, oy, oz, dx, dy, dz; };
