@@ -821,6 +821,7 @@ struct rtmi_ctx {
     int last_reduce_launches = 0;
     int count_traversal = 0;      // option "count_traversal": run the COUNT instantiation of the BVH kernels
     int flat_below = 24;          // option "flat_below": mixed-kind scenes with fewer primitives answer accel = BVH with the flat scan (same image; 3 - 10 % faster there)
+    bool suspend_lanes_set = false; // the option was set by the host (else mixed-kind trees take their own default, see the launch)
     int suspend_lanes = 8;        // option "suspend_lanes": threshold of the time-sliced BVH traversal (0 = plain while-while loop); 6 .. 12 within 0.4 % (C3 69.3 / 69.2 / 69.5 ms at 6 / 10 / 12; 18: 70.7, 24: 73.6)
     hipStream_t last_stream = nullptr; // stream of the most recent render (rtmi_last_traversal_counters synchronises on it)
     long long tile_valid_pixels = 0;
@@ -1019,6 +1020,7 @@ int render_tiles_impl(rtmi_scene *s, int nx, int ny, int ns, int depth, uint64_t
         size_t dyn_lds = 0;
         const size_t bvh_lds = (size_t)(RTMI_BVH_STACK + RTMI_BVH_SUSPEND_WORDS) * kTraceBlock * sizeof(int); // stack columns + suspended cursors
         tp.suspend_lanes = c->suspend_lanes;
+        if (s->dev.has_ext && !c->suspend_lanes_set) tp.suspend_lanes = 12; // make-final, 20 frames each, thresholds 8 / 10 / 12 / 14: 16.22 - 16.30 / 16.16 - 16.21 / 16.12 - 16.20 / 16.21 - 16.22 ms
         if (const char *e = std::getenv("RTMI_SUSPEND_LANES")) tp.suspend_lanes = std::max(0, std::min(64, std::atoi(e)));
         // Mixed-kind kernels: LDS = stack columns for THIS scene's tree (its depth is known: the sphere kernels use the compile-time RTMI_BVH_STACK for their
         // immediate ds_ offsets) + the parked cursors (time-sliced instantiation) + the camera-ray stash (11 words per entry, 17 when the rays' origins differ)
@@ -1853,7 +1855,7 @@ RTMI_EXPORT int rtmi_set_option(rtmi_ctx *c, const char *name, int64_t value) {
     if (!std::strcmp(name, "test_fail_next_render")) { c->fail_next_render = value ? 1 : 0; return RTMI_OK; }
     if (!std::strcmp(name, "test_fail_allocs")) { c->fail_allocs = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64)); return RTMI_OK; }
     if (!std::strcmp(name, "flat_below")) { if (value < 0 || value > (1 << 20)) return fail(RTMI_E_ARG, "flat_below must be 0..2^20"); c->flat_below = (int)value; return RTMI_OK; }
-    if (!std::strcmp(name, "suspend_lanes")) { if (value < 0 || value > 64) return fail(RTMI_E_ARG, "suspend_lanes must be 0..64"); c->suspend_lanes = (int)value; return RTMI_OK; }
+    if (!std::strcmp(name, "suspend_lanes")) { if (value < 0 || value > 64) return fail(RTMI_E_ARG, "suspend_lanes must be 0..64"); c->suspend_lanes = (int)value; c->suspend_lanes_set = true; return RTMI_OK; }
     if (!std::strcmp(name, "accel")) {
         if (value == RTMI_ACCEL_FLAT || value == RTMI_ACCEL_BVH) { c->accel = (int)value; return RTMI_OK; }
         return fail(RTMI_E_UNSUPPORTED, "accel %lld is not available in this build", (long long)value);
