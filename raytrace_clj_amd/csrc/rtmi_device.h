@@ -568,6 +568,74 @@ template <typename R> __device__ inline R perlin_turbulence(SceneRef sc, R px, R
     return acc < R(0) ? -acc : acc;
 }
 
+// Turbulence of the few lanes that need it, evaluated BY THE WAVE.  A marble / turbulence texture is depth x 8 independent lattice terms (perlin.clj:20-64) that
+// the lane's own loop evaluates one after the other -- ~150 instructions per octave while the other lanes of the wave wait: make-final's marble sphere (depth 4, a few
+// per cent of the screen) is hit by one or two lanes of most waves and cost 7 % of the frame.  Here every requesting lane is served in turn (wave-uniform loop over
+// the request mask): its point is broadcast, the ACTIVE lanes each evaluate one (octave, corner) term -- the same operations perlin_noise performs for that corner --
+// into the wave's exchange row in LDS, and the requesting lane adds the terms up in perlin_noise's order (corners dk fastest, the first term assigned) and the octaves
+// in perlin_turbulence's (acc = acc + w * noise from acc = 0, w halved, |acc| at the end): the same additions of the same values, bit for bit.  Four octaves per
+// round (32 terms: the row holds 32 doubles per wave); a point's octave o is 2^o p exactly (v_ldexp: the loop's repeated doubling).
+#define RTMI_TURB_ROUND 4
+#ifndef RTMI_TURB_WAVE_MAX
+#define RTMI_TURB_WAVE_MAX 4 // requests per wave up to which the wave serves them (above: every lane's own loop)
+#endif
+__shared__ double g_turb_xch[4][8 * RTMI_TURB_ROUND]; // [wave of the workgroup: kernels that shade run 256 threads, RTMI_TRACE_BLOCK]
+__device__ inline double perlin_term(SceneRef sc, double px, double py, double pz, int c) { // term c of perlin_noise(p)
+    const double fi = ::floor(px), fj = ::floor(py), fk = ::floor(pz);
+    const int i = (int)fi, j = (int)fj, k = (int)fk;
+    const double u = px - fi, v = py - fj, w = pz - fk;
+    const double uu = (u * u) * (3.0 - 2.0 * u), vv = (v * v) * (3.0 - 2.0 * v), ww = (w * w) * (3.0 - 2.0 * w);
+    const int di = c >> 2, dj = (c >> 1) & 1, dk = c & 1;
+    const int idx = sc.perlin_perm[(i + di) & 255] ^ sc.perlin_perm[256 + ((j + dj) & 255)] ^ sc.perlin_perm[512 + ((k + dk) & 255)];
+    const double *g = sc.perlin_vec + (size_t)idx * 3;
+    const double A = di ? uu : 1.0 - uu, B = dj ? vv : 1.0 - vv, C = dk ? ww : 1.0 - ww;
+    const double d = dot3(u - (double)di, v - (double)dj, w - (double)dk, g[0], g[1], g[2]);
+    return ((A * B) * C) * d;
+}
+__device__ inline double bcast_lane(double x, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+// every ACTIVE lane of the wave must call this together (wave-uniform control flow); lanes with want = false only help.  Returns perlin_turbulence(q, depth) in the
+// lanes that want it.
+__device__ inline double perlin_turbulence_wave(SceneRef sc, bool want, double qx, double qy, double qz, int depth) {
+    unsigned long long req = __ballot(want);
+    if (req == 0) return 0.0;
+    const unsigned long long act = __ballot(1);
+    const int lane = threadIdx.x & 63, nact = __popcll(act), rank = __popcll(act & ((1ull << lane) - 1ull));
+    double *xch = g_turb_xch[threadIdx.x >> 6];
+    double result = 0.0;
+    while (req) { // (wave-uniform)
+        const int r = __ffsll((long long)req) - 1;
+        req &= req - 1;
+        const double bx = bcast_lane(qx, r), by = bcast_lane(qy, r), bz = bcast_lane(qz, r);
+        const int dep = __builtin_amdgcn_readlane(depth, r);
+        double acc = 0.0, wgt = 1.0;
+        for (int o0 = 0; o0 < dep; o0 += RTMI_TURB_ROUND) { // (wave-uniform)
+            const int items = 8 * min(RTMI_TURB_ROUND, dep - o0);
+            for (int w = rank; w < items; w += nact) { // (one trip unless fewer than `items` lanes are active)
+                const int o = o0 + (w >> 3);
+                xch[w] = perlin_term(sc, __builtin_ldexp(bx, o), __builtin_ldexp(by, o), __builtin_ldexp(bz, o), w & 7);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane == r) {
+                for (int q = 0; q < items; q += 8) {
+                    double n = xch[q];
+                    for (int c = 1; c < 8; ++c) n = n + xch[q + c];
+                    acc = acc + wgt * n;
+                    wgt = wgt / 2.0;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier(); // (the next round overwrites the row)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (lane == r) result = acc < 0.0 ? -acc : acc;
+    }
+    return result;
+}
+
 // texture.clj:14-16, 26-34, 44-50 (Texture.sample); checker children are walked iteratively.
 // F4 (only in the EXT kernel instantiations): Perlin noise / turbulence / marble, FlipTextureU/V, ImageMap (texture.clj:60-138)
 template <typename R, bool F4 = false> __device__ inline void tex_sample(SceneRef sc, int t, R u, R v, R px, R py, R pz, R &r, R &g, R &b) {
@@ -2115,9 +2183,29 @@ template <typename R, bool F4 = false> __device__ inline bool scatter_emit(Scene
     }
     // phase 4 -- ONE texture evaluation: emitted of DiffuseLight (shader.clj:118-119) or the albedo of a successful
     // Lambertian / Metal scatter (shader.clj:34,57)
-    if (is_light || is_lamb || is_iso || (is_metal && scat)) {
+    const bool want_tex = is_light || is_lamb || is_iso || (is_metal && scat);
+    double turb = 0.0, turb_p0 = 0.0; // F4: a material whose texture IS a Marble / PerlinTurbulence gets its turbulence from the wave (perlin_turbulence_wave)
+    bool turb_done = false;
+    if (F4 && sizeof(R) == sizeof(double)) { // (wave-uniform: every active lane passes here)
+        const bool want_turb = want_tex && (mtk == RTMI_TEX_MARBLE || mtk == RTMI_TEX_PERLIN_TURB);
+        // ... when FEW lanes ask: a wave whose 64 camera rays all hit the marble sphere evaluates 64 turbulences in its lanes' own loops at full width (~600
+        // instructions for all of them), where serving them one by one would cost 64 rounds; the rounds win below about five requests
+        const int n_turb = __popcll(__ballot(want_turb));
+        if (n_turb > 0 && n_turb <= RTMI_TURB_WAVE_MAX) {
+            double p1 = 0.0;
+            if (want_turb) { const double *tp = sc.tex_param + (size_t)mtex * RTMI_TEX_STRIDE; turb_p0 = tp[0]; p1 = tp[1]; }
+            const double s = mtk == RTMI_TEX_PERLIN_TURB ? turb_p0 : 1.0; // (turbulence (mul scale p) depth) | marble: (turbulence p depth), texture.clj:70-84
+            turb = perlin_turbulence_wave(sc, want_turb, s * (double)px, s * (double)py, s * (double)pz, (int)p1);
+            turb_done = want_turb;
+        }
+    }
+    if (want_tex) {
         R tr, tg, tb;
         if (mtk == RTMI_TEX_CONSTANT) { tr = (R)m1.y; tg = (R)m2.x; tb = (R)m2.y; } // texture.clj:14-16, the colour came with the record
+        else if (F4 && turb_done) {
+            if (mtk == RTMI_TEX_PERLIN_TURB) tr = tg = tb = R(0.5) * ((R)turb + R(1.0));
+            else tr = tg = tb = R(0.5) * (Real<R>::sin_((R)turb_p0 * pz + R(10.0) * (R)turb) + R(1.0));
+        }
         else if (mtk == RTMI_TEX_CHECKER2) { // texture.clj:44-50 with both children Constant
             const double2 m3 = mq[3], m4 = mq[4];
             const R scale = (R)m3.x;
