@@ -408,3 +408,37 @@ def test_mixed_kind_ties_fold_like_the_hitlist(oracle):
                         assert first[0] == 0.0, (pattern, tmax, first[:3])
                 n_checked += 1
     assert n_checked == 16 * 2 * 3
+
+
+def test_turbulence_served_by_the_wave_is_bit_identical(oracle):
+    """perlin_turbulence_wave (a Marble / PerlinTurbulence texture's turbulence evaluated by the whole wave when at most four of its lanes ask: one (octave, corner)
+    term per lane through LDS, added up in perlin.clj's order) against the lanes' own loops (what a wave runs when many lanes ask) and, for PerlinTurbulence (no
+    sin), the oracle: Shader.scatter's attenuation of the same hit records, bit for bit, whether they come one to four per launch (the wave serves them; with
+    three active lanes every lane evaluates eleven terms) or 64 per wave.  Depths 1, 4, 7 (two rounds of four octaves) and 9 (three)."""
+    T, S, H = r.texture, r.shader, r.hitable
+    vec3 = lambda *a: np.array(a, np.float64)
+    texs = [T.perlin_turbulence(scale=4, depth=7), T.perlin_turbulence(scale=0.7, depth=1), T.perlin_turbulence(scale=2.5, depth=9), T.perlin_turbulence(scale=1.0, depth=4),
+            T.marble(scale=0.1, depth=4), T.marble(scale=3.0, depth=7)]
+    world = H.hitlist(items=[H.sphere(center=vec3(3 * k, 0, 0), radius=1.0, material=S.lambertian(albedo=t)) for k, t in enumerate(texs)])
+    f = fl.flatten(world, r.camera.PinholeCamera(*(np.zeros(3),) * 4))
+    rng = np.random.default_rng(17)
+    n = 256
+    p = rng.normal(0, 40, (n, 3))
+    p[:16] = np.round(p[:16])  # lattice points
+    nrm = rng.normal(0, 1, (n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    hits = np.concatenate([p, nrm, rng.random((n, 2))], axis=1)
+    rays = np.concatenate([p - nrm, -nrm + 0.1 * rng.normal(0, 1, (n, 3)), rng.random((n, 1))], axis=1)
+    keys = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+    ds = core.DeviceScene(f)
+    for m, t in enumerate(texs):
+        dense = ds.probe_scatter(m, rays, hits, keys)  # 64 requests per wave: every lane's own loop
+        assert np.all(dense[:, 0] == 1.0)
+        for lo, cnt in ((0, 1), (1, 2), (3, 3), (6, 4), (100, 3), (250, 1)):  # <= 4 requests in the launch's one wave: served by the wave
+            few = ds.probe_scatter(m, rays[lo:lo + cnt], hits[lo:lo + cnt], keys[lo:lo + cnt])
+            assert np.array_equal(few, dense[lo:lo + cnt]), (type(t).__name__, t.depth, lo, cnt)
+        five = ds.probe_scatter(m, rays[10:15], hits[10:15], keys[10:15])  # five requests: the lanes' own loops again
+        assert np.array_equal(five, dense[10:15])
+        if isinstance(t, T.PerlinTurbulence):
+            exp = oracle.probe_scatter(f, m, rays, hits, keys)
+            assert np.array_equal(dense, exp), (t.scale, t.depth)
+    ds.close()
