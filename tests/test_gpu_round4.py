@@ -442,3 +442,10 @@ def test_turbulence_served_by_the_wave_is_bit_identical(oracle):
             exp = oracle.probe_scatter(f, m, rays, hits, keys)
             assert np.array_equal(dense, exp), (t.scale, t.depth)
     ds.close()
+
+
+def test_mixed_kind_soak_short():
+    """scripts/gpu_soak_ext.py at a size that takes seconds: random mixed-kind worlds, adversarial rays (corners, edges, plane origins, axis-parallel, huge / tiny /
+    non-finite), every device path the same bits, Hitlist worlds = the nested oracle, bvh worlds = the Hitlist semantics"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_soak_ext.py"), "30000", "6"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "SOAK-EXT PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
