@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <map>
 #include <mutex>
 #include <new>
@@ -196,7 +197,7 @@ __device__ inline void intersect_ext(SceneRef sc, int *stack, bool bvh, Path<dou
     // calls the media (and draws).  A resumed lane (time-sliced traversal) evaluated its media when its segment began; they ride in its parked hit state.
     if (!(SLICED && bvh && *mid)) {
         MediumChord chord = medium_chord_begin(P);
-        for (int k = 0; k < sc.n_media; ++k) ext_medium_test(sc, sc.media_idx[k], P, tmin, tmax, H, chord, COUNT ? cnt : nullptr);
+        for (int k = 0; k < sc.n_media; ++k) ext_medium_test(sc, sc.media_idx[k], P, tmin, tmax, H, chord, COUNT ? cnt : nullptr, nullptr, k);
         RTMI_PH(PH_MEDIA)
     }
     if (bvh) {
@@ -844,6 +845,7 @@ struct rtmi_scene {
     int max_image = -1;       // highest ImageMap index: rtmi_scene_set_images must cover it
     bool have_perlin = false;
     std::vector<int> host_kind; // primitive kinds (boundary flag removed), for argument checks
+    std::map<int, std::array<double, 5>> media_fast_of; // medium primitive -> {density, c.xyz, r*r} when it and its boundary are one plain sphere without wrappers (DevScene::media_fast)
     // the caller's arrays, copied at creation (the library keeps no host POINTERS): what rtmi_scene_clone replicates
     struct Args {
         std::vector<int32_t> prim_kind, prim_mat, mat_kind, mat_tex, tex_kind, tex_child, prim_flip, prim_xform, xform_kind, perm, media_calls, media_lo, image_wh;
@@ -1881,6 +1883,18 @@ RTMI_EXPORT int rtmi_scene_create(rtmi_ctx *c, int32_t n_prims, const int32_t *p
                                 cam_kind, cam, nullptr, nullptr, 0, nullptr, nullptr, out_scene);
 }
 
+// DevScene::media_fast follows the media call sequence
+static void fill_media_fast(rtmi_scene *s) {
+    for (int k = 0; k < 8; ++k) {
+        double *q = s->dev.media_fast[k];
+        for (int j = 0; j < 8; ++j) q[j] = 0.0;
+        if (k >= s->dev.n_media) continue;
+        const auto it = s->media_fast_of.find(s->dev.media_idx[k]);
+        if (it == s->media_fast_of.end()) continue;
+        q[0] = 1.0;
+        for (int j = 0; j < 5; ++j) q[1 + j] = it->second[(size_t)j];
+    }
+}
 RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t *prim_kind, const double *prim_geom, const int32_t *prim_mat,
                                      int32_t n_mats, const int32_t *mat_kind, const int32_t *mat_tex, const double *mat_param,
                                      int32_t n_tex, const int32_t *tex_kind, const double *tex_param, const int32_t *tex_child,
@@ -2275,6 +2289,15 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
     if (!rc) rc = upload(s, tk, &d.tex_kind);
     if (!rc) rc = upload(s, tpv, &d.tex_param);
     if (!rc) rc = upload(s, tc, &d.tex_child);
+    for (int k = 0; k < n_media; ++k) { // media whose boundary is one plain sphere, neither under wrappers: their operands go into the descriptor (media_fast)
+        const int m = media[k];
+        const int fb = (int)prim_geom[(size_t)m * RTMI_PRIM_STRIDE + 1], nb = (int)prim_geom[(size_t)m * RTMI_PRIM_STRIDE + 2];
+        if (nb != 1 || fb < 0 || fb >= n_prims) continue;
+        if (pk[(size_t)fb] != RTMI_PRIM_SPHERE && pk[(size_t)fb] != RTMI_PRIM_UVSPHERE) continue;
+        if (prim_xform && (prim_xform[2 * m + 1] != 0 || prim_xform[2 * fb + 1] != 0)) continue;
+        s->media_fast_of[m] = {exact12[(size_t)m * 12], exact12[(size_t)fb * 12], exact12[(size_t)fb * 12 + 1], exact12[(size_t)fb * 12 + 2], exact12[(size_t)fb * 12 + 3]};
+    }
+    fill_media_fast(s);
     if (!rc) {
         std::vector<DevScene> one(1, d);
         const DevScene *dp = nullptr;
@@ -2303,6 +2326,7 @@ RTMI_EXPORT int rtmi_scene_create_ex(rtmi_ctx *c, int32_t n_prims, const int32_t
 
 namespace {
 int reupload_descriptor(rtmi_scene *s) {
+    fill_media_fast(s);
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
     HIP_TRY(hipMemcpy((void *)s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice));
     return RTMI_OK;

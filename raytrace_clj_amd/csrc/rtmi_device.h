@@ -70,6 +70,9 @@ struct DevScene {
     int media_seq;           // RTMI_MEDIA_HITLIST: the world is a Hitlist (hitable.clj:15-26), a medium's hit? sees the t-max narrowed by the items before it
     int n_media;             // hit? invocations of ConstantMedium primitives (hitable.clj:516) per ray, in the reference's call order
     int media_idx[32];       // (a medium may appear twice: rtmi_scene_set_media_calls); exact12 = density, first boundary prim, count
+    // media calls 0 .. RTMI_MEDIA_FAST_MAX - 1 whose medium and boundary are ONE plain sphere without wrappers (make-final's two media): {1, density, c.xyz, r*r, -, -} in the
+    // descriptor itself -- one scalar load where ext_medium_chord chases exact12[medium] -> ext_info[boundary] -> exact12[boundary]; {0, ...}: the general path
+    double media_fast[8][8];
     // section 8(f4): perlin.clj:6-17 tables (seeded scene data) and ImageMap pixels (texture.clj:126-133)
     const double *perlin_vec; // [256][3]
     const int *perlin_perm;   // [3][256]
@@ -1672,23 +1675,52 @@ __device__ inline void scan_small_ext(SceneRef sc, const Path<double> &P, double
 // refined-reciprocal form (RefinedRcp: the IEEE sequence's own last three operations, the same bits while the division would not rescale its operands: checked per
 // lane, numerator and divisor; anything else divides).  For a medium without an instance chain a, |d| and their reciprocals are the RAY's: medium_chord_begin
 // evaluates them once per segment for all media calls (make-final: three calls, two media; 12 divisions and 2 square roots per segment before).
-struct MediumChord { int idx; bool ok; double t1, t2, mag, rmag, rden; double ray_a, ray_ra, ray_mag, ray_rmag; };
+struct MediumChord { int idx; bool ok; double t1, t2, mag, rmag, rden, density; double ray_a, ray_ra, ray_mag, ray_rmag; };
 __device__ inline bool num_in_range(double n) { return ((unsigned)__double2hiint(n) & 0x7fffffffu) - (54u << 20) < (1537u << 20); } // 2^-969 <= |n| < 2^568
 __device__ inline MediumChord medium_chord_begin(const Path<double> &P) {
     MediumChord C;
-    C.idx = -1; C.ok = false; C.t1 = C.t2 = C.mag = C.rmag = C.rden = 0.0;
+    C.idx = -1; C.ok = false; C.t1 = C.t2 = C.mag = C.rmag = C.rden = C.density = 0.0;
     C.ray_a = dot3(P.dx, P.dy, P.dz, P.dx, P.dy, P.dz);
     C.ray_ra = refined_rcp(C.ray_a).r;
     C.ray_mag = rt_sqrt(C.ray_a);
     C.ray_rmag = refined_rcp(C.ray_mag).r;
     return C;
 }
-__device__ inline void ext_medium_chord(SceneRef sc, int idx, const Path<double> &P, MediumChord &C, unsigned *cnt = nullptr) {
+#define RTMI_MEDIA_FAST_MAX 8
+__device__ inline void ext_medium_chord(SceneRef sc, int idx, const Path<double> &P, MediumChord &C, unsigned *cnt = nullptr, int k = -1) {
     const double FMAX = 3.4028234663852886e38;
+    if (k >= 0 && k < RTMI_MEDIA_FAST_MAX && sc.media_fast[k][0] != 0.0) { // (wave-uniform) the one-sphere branch below with its operands from the descriptor
+        C.idx = idx; C.ok = false; C.t1 = C.t2 = C.mag = C.rmag = 0.0;
+        C.density = sc.media_fast[k][1];
+        C.rden = refined_rcp(C.density).r;
+        Prim4<double> s;
+        s.cx = sc.media_fast[k][2]; s.cy = sc.media_fast[k][3]; s.cz = sc.media_fast[k][4]; s.r2 = sc.media_fast[k][5];
+        const RefinedRcp qa = {C.ray_a, C.ray_ra};
+        const bool fa = rcp_in_range(qa.a);
+        double bq, cq, disc;
+        sphere_test(s, P, qa.a, bq, cq, disc);
+        if (!(disc >= 0.0)) { if (cnt) cnt[1] += 1u; return; }
+        const double sq = rt_sqrt(disc);
+        const double nA = -bq - sq;
+        const double tA = div_by(nA, qa, fa && num_in_range(nA));
+        const double tmin2 = tA + 0.0001;
+        if (tA > -FMAX && tA < FMAX && !(tA > tmin2)) {
+            if (cnt) cnt[1] += 2u;
+            if (tmin2 >= 0.0 && bq > 0.0 && cq > 0.0) return;
+            const double nB = -bq + sq;
+            const double tB = div_by(nB, qa, fa && num_in_range(nB));
+            if (!(tB > tmin2 && tB < FMAX)) return;
+            C.mag = C.ray_mag; C.rmag = C.ray_rmag;
+            C.t1 = tA; C.t2 = tB; C.ok = true;
+            return;
+        }
+        // (a root that is not finite: the generic scans below)
+    }
     const size_t gi = (size_t)idx * 12; // idx comes from media_idx: wave-uniform
     const int first = (int)ext_ld<true>(sc.exact12, gi + 1), count = (int)ext_ld<true>(sc.exact12, gi + 2);
     C.idx = idx; C.ok = false; C.t1 = C.t2 = C.mag = C.rmag = 0.0;
-    C.rden = refined_rcp(ext_ld<true>(sc.exact12, gi)).r;
+    C.density = ext_ld<true>(sc.exact12, gi);
+    C.rden = refined_rcp(C.density).r;
     const int4 info = ext_ld_info<true>(sc.ext_info, idx);
     auto own_mag = [&]() { // |d| of the ray as the medium sees it (its own chain; none: the ray's)
         if (info.w == 0) { C.mag = C.ray_mag; C.rmag = C.ray_rmag; return; }
@@ -1743,15 +1775,16 @@ __device__ inline void ext_medium_chord(SceneRef sc, int idx, const Path<double>
     C.t1 = h1.t; C.t2 = h2.t; C.ok = true;
 }
 // hit_t (optional): receives the medium's hit parameter when it hits (the return value says whether)
-__device__ inline bool ext_medium_test(SceneRef sc, int idx, Path<double> &P, double tmin, double tmax, ExtHit &H, MediumChord &C, unsigned *cnt = nullptr, double *hit_t = nullptr) {
-    if (C.idx != idx) ext_medium_chord(sc, idx, P, C, cnt); // (wave-uniform)
+// k (optional): the call's position in the media sequence (media_fast)
+__device__ inline bool ext_medium_test(SceneRef sc, int idx, Path<double> &P, double tmin, double tmax, ExtHit &H, MediumChord &C, unsigned *cnt = nullptr, double *hit_t = nullptr, int k = -1) {
+    if (C.idx != idx) ext_medium_chord(sc, idx, P, C, cnt, k); // (wave-uniform)
     if (!C.ok) return false;
     double t1 = C.t1, t2 = C.t2;
     if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
     if (!(t1 < t2)) return false;
     if (t1 < 0.0) t1 = 0.0;
-    const RefinedRcp qd = {ext_ld<true>(sc.exact12, (size_t)idx * 12), C.rden}, qm = {C.mag, C.rmag};
+    const RefinedRcp qd = {C.density, C.rden}, qm = {C.mag, C.rmag};
     const double dist_in = (t2 - t1) * C.mag;
     const double lg = rt_log_unit(next_uniform(P));
     const double hit_distance = -div_by(lg, qd, rcp_in_range(qd.a) && num_in_range(lg));
